@@ -1,0 +1,125 @@
+// A2: fused distance + Gaussian RBF + cosine cutoff, forward and backward.
+// Replaces the reference's fused_distance_gaussian_rbf_cutoff (kernels/cfconv_kernels.py:1578-1656)
+// and the backward formula at :1696-1733.  HBM-bound: the [E,R] fp32 expansion is the traffic;
+// a wave owns 64 consecutive edges and writes/reads their 64*R values as one contiguous stream.
+#include "fmd_common.h"
+
+namespace {
+
+constexpr int RBF_WAVES = 4;
+
+__global__ __launch_bounds__(RBF_WAVES * 64) void rbf_fwd_kernel(
+    const float* __restrict__ pos, const int64_t* __restrict__ esrc, const int64_t* __restrict__ edst,
+    const float* __restrict__ centers, float gamma, float rc, int64_t n_edges, int n_rbf,
+    float* __restrict__ dist, float* __restrict__ rbf) {
+  __shared__ float sd[RBF_WAVES][64], sc[RBF_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e0 = ((int64_t)blockIdx.x * RBF_WAVES + wave) * 64;
+  if (e0 >= n_edges) return;
+  const int64_t e = e0 + lane;
+  float d = 0.f, c = 0.f;
+  if (e < n_edges) {
+    const int64_t s = esrc[e], t = edst[e];
+    const float dx = pos[3 * t] - pos[3 * s], dy = pos[3 * t + 1] - pos[3 * s + 1],
+                dz = pos[3 * t + 2] - pos[3 * s + 2];
+    d = sqrtf(dx * dx + dy * dy + dz * dz);
+    c = fmd_cutoff(d, rc);
+    dist[e] = d;
+  }
+  sd[wave][lane] = d;
+  sc[wave][lane] = c;
+  // same-wave LDS write -> read: program order + waitcnt is enough, no barrier needed
+  const int ne = (int)min((int64_t)64, n_edges - e0);
+  const int total = ne * n_rbf;
+  float* out = rbf + e0 * n_rbf;
+  for (int t = lane; t < total; t += 64) {
+    const int el = t / n_rbf, k = t - el * n_rbf;
+    const float diff = sd[wave][el] - centers[k];
+    out[t] = __expf(gamma * diff * diff) * sc[wave][el];
+  }
+}
+
+// grad wrt distance, then scattered onto the two end points with float atomics (the reference
+// uses index_add_, equally unordered).
+__global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
+    const float* __restrict__ pos, const int64_t* __restrict__ esrc, const int64_t* __restrict__ edst,
+    const float* __restrict__ centers, float gamma, float rc, int64_t n_edges, int n_rbf,
+    const float* __restrict__ dist, const float* __restrict__ gdist, const float* __restrict__ grbf,
+    float* __restrict__ gpos) {
+  __shared__ float sd[RBF_WAVES][64], sc[RBF_WAVES][64], sdc[RBF_WAVES][64], sacc[RBF_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e0 = ((int64_t)blockIdx.x * RBF_WAVES + wave) * 64;
+  if (e0 >= n_edges) return;
+  const int64_t e = e0 + lane;
+  float d = 0.f, c = 0.f, dc = 0.f;
+  if (e < n_edges) {
+    d = dist[e];
+    fmd_cutoff2(d, rc, c, dc);
+  }
+  sd[wave][lane] = d;
+  sc[wave][lane] = c;
+  sdc[wave][lane] = dc;
+  sacc[wave][lane] = 0.f;
+  if (grbf) {
+    const int ne = (int)min((int64_t)64, n_edges - e0);
+    const int total = ne * n_rbf;
+    const float* g = grbf + e0 * n_rbf;
+    for (int t = lane; t < total; t += 64) {
+      const int el = t / n_rbf, k = t - el * n_rbf;
+      const float diff = sd[wave][el] - centers[k];
+      const float ex = __expf(gamma * diff * diff);
+      // d rbf / d d = 2 gamma diff ex C + ex C'            (cfconv_kernels.py:1716-1719)
+      const float dr = ex * (2.0f * gamma * diff * sc[wave][el] + sdc[wave][el]);
+      atomicAdd(&sacc[wave][el], g[t] * dr);  // LDS float atomic
+    }
+  }
+  if (e < n_edges) {
+    float gd = sacc[wave][lane];
+    if (gdist) gd += gdist[e];
+    const int64_t s = esrc[e], t = edst[e];
+    const float dx = pos[3 * t] - pos[3 * s], dy = pos[3 * t + 1] - pos[3 * s + 1],
+                dz = pos[3 * t + 2] - pos[3 * s + 2];
+    const float inv = gd / fmaxf(d, 1e-8f);  // clamp as cfconv_kernels.py:1697
+    const float gx = dx * inv, gy = dy * inv, gz = dz * inv;
+    atomicAdd(&gpos[3 * t], gx);
+    atomicAdd(&gpos[3 * t + 1], gy);
+    atomicAdd(&gpos[3 * t + 2], gz);
+    atomicAdd(&gpos[3 * s], -gx);
+    atomicAdd(&gpos[3 * s + 1], -gy);
+    atomicAdd(&gpos[3 * s + 2], -gz);
+  }
+}
+
+}  // namespace
+
+extern "C" int fmd_distance_rbf_cutoff_fwd(const float* pos, const int64_t* edge_src,
+                                           const int64_t* edge_dst, const float* centers, float gamma,
+                                           float cutoff, int64_t n_edges, int64_t n_rbf, float* dist,
+                                           float* rbf, void* stream) {
+  if (n_edges < 0 || n_rbf <= 0 || n_rbf > 65536) return FMD_EINVAL;
+  if (n_edges == 0) return FMD_OK;
+  if (!pos || !edge_src || !edge_dst || !centers || !dist || !rbf) return FMD_EINVAL;
+  const int64_t nblk = (n_edges + RBF_WAVES * 64 - 1) / (RBF_WAVES * 64);
+  rbf_fwd_kernel<<<(unsigned)nblk, RBF_WAVES * 64, 0, fmd_stream(stream)>>>(
+      pos, edge_src, edge_dst, centers, gamma, cutoff, n_edges, (int)n_rbf, dist, rbf);
+  FMD_CHECK_LAUNCH();
+  return FMD_OK;
+}
+
+extern "C" int fmd_distance_rbf_cutoff_bwd(const float* pos, const int64_t* edge_src,
+                                           const int64_t* edge_dst, const float* centers, float gamma,
+                                           float cutoff, int64_t n_edges, int64_t n_rbf,
+                                           int64_t n_nodes, const float* dist, const float* grad_dist,
+                                           const float* grad_rbf, float* grad_pos, void* stream) {
+  if (n_edges < 0 || n_rbf <= 0 || n_nodes < 0 || !grad_pos) return FMD_EINVAL;
+  hipStream_t s = fmd_stream(stream);
+  if (hipMemsetAsync(grad_pos, 0, sizeof(float) * 3 * n_nodes, s) != hipSuccess) return FMD_ELAUNCH;
+  if (n_edges == 0) return FMD_OK;
+  if (!pos || !edge_src || !edge_dst || !centers || !dist) return FMD_EINVAL;
+  const int64_t nblk = (n_edges + RBF_WAVES * 64 - 1) / (RBF_WAVES * 64);
+  rbf_bwd_kernel<<<(unsigned)nblk, RBF_WAVES * 64, 0, s>>>(pos, edge_src, edge_dst, centers, gamma,
+                                                         cutoff, n_edges, (int)n_rbf, dist, grad_dist,
+                                                         grad_rbf, grad_pos);
+  FMD_CHECK_LAUNCH();
+  return FMD_OK;
+}

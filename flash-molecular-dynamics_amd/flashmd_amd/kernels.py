@@ -1,0 +1,621 @@
+"""Operator surface of the MI355X CGSchNet path -- same names, argument order, defaults and error
+behaviour as the reference's ``flashmd.kernels`` (reference src/flashmd/kernels/__init__.py:12-75),
+so ``from flashmd_amd.kernels import ...`` replaces ``from flashmd.kernels... import ...`` at
+reference models/schnet.py:29-38 and models/gptq.py:19-22.
+
+Every function enqueues hand-written HIP kernels (csrc/*.hip) through the C ABI of
+include/flashmd_hip.h on torch's current stream; results are freshly allocated torch tensors,
+inputs are never modified.  There is no Triton, no torch.compile and no CPU fallback here.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * the CFConv autograd functions return the gradient w.r.t. ``edge_weight`` (distances) --
+    the reference's Triton path returns None there while its PyTorch path, which is
+    the parity target, differentiates the cutoff (models/schnet.py:710-713);
+  * the fused-RBF backward runs (the reference's raises NameError);
+  * ``build_csr_index`` returns the stable (ascending edge id) permutation, one deterministic
+    member of the set the reference's atomic-cursor fill can produce.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _ffi
+from ._ffi import call, ptr, stream
+
+__all__ = [
+    "radius_graph",
+    "fused_cutoff_gather_multiply_scatter_kernel", "fused_cutoff_gather_multiply_scatter",
+    "fused_cutoff_gather_multiply_scatter_autograd", "fused_grad_filter_out",
+    "fused_linear_tanh_kernel", "fused_linear_tanh", "fused_linear_tanh_autograd",
+    "fused_linear_tanh_fp16_kernel", "fused_linear_tanh_fp16", "fused_linear_tanh_fp16_autograd",
+    "linear_fp16_kernel", "linear_fp16", "linear_fp16_autograd",
+    "fused_distance_gaussian_rbf_cutoff_kernel", "fused_distance_gaussian_rbf_cutoff",
+    "fused_distance_gaussian_rbf_cutoff_autograd",
+    "fused_tanh_linear_kernel", "fused_tanh_linear", "fused_tanh_linear_autograd",
+    "build_csr_index", "build_src_csr_index", "fused_csr_cfconv", "fused_csr_cfconv_autograd",
+    "fused_src_csr_grad_x", "csr_segment_reduce",
+    "fused_tanh_backward_grad_x_v2", "matmul_fp32_fp16_to_fp16_v2", "gemm_f32",
+]
+
+
+class _CKernel:
+    """Stands where the reference exports a ``@triton.jit`` object: names the C entry point."""
+
+    def __init__(self, c_symbol: str):
+        self.c_symbol = c_symbol
+
+    def __repr__(self):
+        return f"<HIP kernel behind {self.c_symbol}>"
+
+
+fused_cutoff_gather_multiply_scatter_kernel = _CKernel("fmd_cfconv_scatter_atomic")
+fused_linear_tanh_kernel = _CKernel("fmd_gemm_f32")
+fused_linear_tanh_fp16_kernel = _CKernel("fmd_linear_tanh_f16")
+linear_fp16_kernel = _CKernel("fmd_linear_f16")
+fused_distance_gaussian_rbf_cutoff_kernel = _CKernel("fmd_distance_rbf_cutoff_fwd")
+fused_tanh_linear_kernel = _CKernel("fmd_gemm_f32")
+
+PRO_NONE, PRO_TANH = 0, 1
+EPI_NONE, EPI_TANH, EPI_MUL_DTANH = 0, 1, 2
+
+
+def _aligned(t: torch.Tensor) -> torch.Tensor:
+    """16-byte aligned contiguous storage for the vector loads (a sliced view may not be)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+# ==================================================================================================
+# A1  neighbour list (replaces torch_cluster.radius_graph, reference neighbor_list/torch_impl.py:216-224)
+# ==================================================================================================
+
+
+def radius_graph(pos: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None,
+                 loop: bool = False, max_num_neighbors: int = 1000,
+                 flow: str = "target_to_source", num_workers: int = 1,
+                 ptr_: Optional[torch.Tensor] = None,
+                 max_beads_per_mol: int = 0) -> torch.Tensor:
+    """edge_index[2,E] int64: rows [centre i, neighbour j] of all pairs inside one molecule with
+    |r_j - r_i| < r (strict), sorted by centre then neighbour.  ``ptr_`` (data.ptr) avoids deriving
+    molecule boundaries from ``batch``.  Truncation to ``max_num_neighbors`` is not applied (the
+    reference passes 1000, above any CG molecule's degree); ``loop=True`` is not supported."""
+    _ffi.require_gpu(pos)
+    assert pos.dim() == 2 and pos.shape[1] == 3 and pos.dtype == torch.float32
+    if loop:
+        raise NotImplementedError("radius_graph(loop=True) is not part of the SchNet path")
+    if flow != "target_to_source":
+        raise NotImplementedError("only flow='target_to_source' (the reference's call) is built")
+    pos = pos.detach().contiguous()
+    n = pos.shape[0]
+    if ptr_ is None:
+        if batch is None:
+            ptr_ = torch.tensor([0, n], dtype=torch.int64, device=pos.device)
+        else:
+            n_mol = int(batch[-1].item()) + 1 if n > 0 else 0
+            counts = torch.bincount(batch, minlength=n_mol)
+            ptr_ = torch.zeros(n_mol + 1, dtype=torch.int64, device=pos.device)
+            ptr_[1:] = counts.cumsum(0)
+    ptr_ = ptr_.to(torch.int64).contiguous()
+    n_mol = ptr_.numel() - 1
+    deg = torch.empty(n, dtype=torch.int32, device=pos.device)
+    row_ptr = torch.empty(n + 1, dtype=torch.int64, device=pos.device)
+    call("fmd_radius_graph_count", ptr(pos), ptr(ptr_), n_mol, n, int(max_beads_per_mol), float(r),
+         ptr(deg), ptr(row_ptr), stream())
+    n_edges = int(row_ptr[-1].item())  # the one host sync, as in torch_cluster
+    edge_index = torch.empty((2, n_edges), dtype=torch.int64, device=pos.device)
+    if n_edges:
+        call("fmd_radius_graph_fill", ptr(pos), ptr(ptr_), n_mol, n, int(max_beads_per_mol),
+             float(r), ptr(row_ptr), ptr(edge_index[0]), ptr(edge_index[1]), stream())
+    return edge_index
+
+
+# ==================================================================================================
+# A2  distance + Gaussian RBF + cosine cutoff (reference kernels/cfconv_kernels.py:1578-1749)
+# ==================================================================================================
+
+
+def fused_distance_gaussian_rbf_cutoff(pos, edge_src, edge_dst, centers, gamma: float,
+                                       cutoff_upper: float) -> tuple:
+    assert pos.is_cuda and pos.is_contiguous()
+    assert edge_src.is_contiguous()
+    assert edge_dst.is_contiguous()
+    assert centers.is_contiguous()
+    assert pos.dtype == torch.float32, "the HIP path computes in fp32"
+    num_edges, num_rbf = edge_src.shape[0], centers.shape[0]
+    distances = torch.empty(num_edges, device=pos.device, dtype=pos.dtype)
+    rbf_output = torch.empty((num_edges, num_rbf), device=pos.device, dtype=pos.dtype)
+    if num_edges == 0:
+        return distances, rbf_output
+    call("fmd_distance_rbf_cutoff_fwd", ptr(pos), ptr(edge_src), ptr(edge_dst), ptr(centers),
+         float(gamma), float(cutoff_upper), num_edges, num_rbf, ptr(distances), ptr(rbf_output),
+         stream())
+    return distances, rbf_output
+
+
+class FusedDistanceGaussianRBFCutoffFunction(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:1659-1735"""
+
+    @staticmethod
+    def forward(ctx, pos, edge_src, edge_dst, centers, gamma, cutoff_upper):
+        distances, rbf = fused_distance_gaussian_rbf_cutoff(pos, edge_src, edge_dst, centers, gamma,
+                                                            cutoff_upper)
+        ctx.save_for_backward(pos, edge_src, edge_dst, centers, distances)
+        ctx.gamma, ctx.cutoff_upper = gamma, cutoff_upper
+        return distances, rbf
+
+    @staticmethod
+    def backward(ctx, grad_distances, grad_rbf):
+        pos, edge_src, edge_dst, centers, distances = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None
+        grad_pos = torch.empty_like(pos)
+        gd = grad_distances.contiguous() if grad_distances is not None else None
+        gr = grad_rbf.contiguous() if grad_rbf is not None else None
+        call("fmd_distance_rbf_cutoff_bwd", ptr(pos), ptr(edge_src), ptr(edge_dst), ptr(centers),
+             float(ctx.gamma), float(ctx.cutoff_upper), edge_src.shape[0], centers.shape[0],
+             pos.shape[0], ptr(distances), ptr(gd), ptr(gr), ptr(grad_pos), stream())
+        return grad_pos, None, None, None, None, None
+
+
+def fused_distance_gaussian_rbf_cutoff_autograd(pos, edge_src, edge_dst, centers, gamma: float,
+                                                cutoff_upper: float) -> tuple:
+    return FusedDistanceGaussianRBFCutoffFunction.apply(pos, edge_src, edge_dst, centers, gamma,
+                                                        cutoff_upper)
+
+
+# ==================================================================================================
+# A3  CSR build (reference kernels/csr_kernels.py:88-169, 229-294)
+# ==================================================================================================
+
+
+def _build_csr(keys: torch.Tensor, num_nodes: int):
+    _ffi.require_gpu(keys)
+    assert keys.dtype == torch.int64 and keys.is_contiguous()
+    num_edges, device = keys.shape[0], keys.device
+    if num_edges == 0:  # reference :132-137
+        return (torch.zeros(num_nodes + 1, dtype=torch.int64, device=device),
+                torch.empty(0, dtype=torch.int64, device=device))
+    ptr_out = torch.empty(num_nodes + 1, dtype=torch.int64, device=device)
+    perm = torch.empty(num_edges, dtype=torch.int64, device=device)
+    nbytes = _ffi.lib().fmd_build_csr_workspace_bytes(num_nodes, num_edges)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    call("fmd_build_csr", ptr(keys), num_edges, num_nodes, ptr(ptr_out), ptr(perm), ptr(ws), stream())
+    return ptr_out, perm
+
+
+def build_csr_index(edge_dst: torch.Tensor, num_nodes: int, edge_src: torch.Tensor = None) -> tuple:
+    dst_ptr, csr_perm = _build_csr(edge_dst, num_nodes)
+    if edge_src is not None:
+        return dst_ptr, csr_perm, edge_src[csr_perm]
+    return dst_ptr, csr_perm
+
+
+def build_src_csr_index(edge_src: torch.Tensor, num_nodes: int) -> tuple:
+    return _build_csr(edge_src, num_nodes)
+
+
+# ==================================================================================================
+# A5/A6  CFConv message passing
+# ==================================================================================================
+
+
+def _check_filt(filter_out):
+    assert filter_out.dtype in (torch.float32, torch.float16)
+    return 1 if filter_out.dtype == torch.float16 else 0
+
+
+def fused_csr_cfconv(x, filter_out, edge_weight, edge_src, dst_ptr, csr_perm, num_nodes: int,
+                     cutoff_upper: float) -> torch.Tensor:
+    """reference kernels/csr_kernels.py:727-810"""
+    assert x.is_cuda and x.is_contiguous()
+    assert filter_out.is_contiguous()
+    assert edge_weight.is_contiguous()
+    assert edge_src.is_contiguous()
+    assert dst_ptr.is_contiguous()
+    assert csr_perm.is_contiguous()
+    feature_dim = x.shape[1]
+    num_edges = edge_src.shape[0]
+    if num_edges == 0:
+        return torch.zeros(num_nodes, feature_dim, device=x.device, dtype=x.dtype)
+    output = torch.empty(num_nodes, feature_dim, device=x.device, dtype=torch.float32)
+    x, filter_out = _aligned(x), _aligned(filter_out)
+    call("fmd_csr_cfconv_fwd", ptr(x), ptr(filter_out), _check_filt(filter_out), ptr(edge_weight),
+         ptr(edge_src), ptr(dst_ptr), ptr(csr_perm), num_nodes, feature_dim, float(cutoff_upper),
+         ptr(output), stream())
+    return output
+
+
+def fused_src_csr_grad_x(grad_output, filter_out, edge_weight, edge_dst, src_ptr, src_perm,
+                         num_nodes: int, cutoff_upper: float) -> torch.Tensor:
+    """reference kernels/csr_kernels.py:399-482: the same segment reduce keyed by source node."""
+    assert grad_output.is_cuda and grad_output.is_contiguous()
+    assert filter_out.is_contiguous()
+    assert edge_weight.is_contiguous()
+    assert edge_dst.is_contiguous()
+    assert src_ptr.is_contiguous()
+    assert src_perm.is_contiguous()
+    feature_dim = grad_output.shape[1]
+    if edge_dst.shape[0] == 0:
+        return torch.zeros(num_nodes, feature_dim, device=grad_output.device, dtype=torch.float32)
+    grad_x = torch.empty(num_nodes, feature_dim, device=grad_output.device, dtype=torch.float32)
+    grad_output, filter_out = _aligned(grad_output), _aligned(filter_out)
+    call("fmd_csr_cfconv_fwd", ptr(grad_output), ptr(filter_out), _check_filt(filter_out),
+         ptr(edge_weight), ptr(edge_dst), ptr(src_ptr), ptr(src_perm), num_nodes, feature_dim,
+         float(cutoff_upper), ptr(grad_x), stream())
+    return grad_x
+
+
+def csr_segment_reduce(msg, dst_ptr, csr_perm, num_nodes: int) -> torch.Tensor:
+    """reference kernels/csr_kernels.py:559-617"""
+    assert msg.is_cuda and msg.is_contiguous()
+    assert dst_ptr.is_cuda and dst_ptr.is_contiguous()
+    assert csr_perm.is_cuda and csr_perm.is_contiguous()
+    assert msg.dtype == torch.float32
+    num_edges, feature_dim = msg.shape
+    if num_edges == 0:
+        return torch.zeros(num_nodes, feature_dim, device=msg.device, dtype=msg.dtype)
+    output = torch.empty(num_nodes, feature_dim, device=msg.device, dtype=msg.dtype)
+    call("fmd_csr_segment_reduce", ptr(_aligned(msg)), ptr(dst_ptr), ptr(csr_perm), num_nodes,
+         feature_dim, ptr(output), stream())
+    return output
+
+
+def fused_cutoff_gather_multiply_scatter(x, filter_out, edge_weight, edge_src, edge_dst,
+                                         num_nodes: int, cutoff_upper: float) -> torch.Tensor:
+    """reference kernels/cfconv_kernels.py:93-170 (atomic scatter variant)"""
+    assert x.is_cuda and x.is_contiguous()
+    assert filter_out.is_contiguous()
+    assert edge_weight.is_contiguous()
+    assert edge_src.is_contiguous()
+    assert edge_dst.is_contiguous()
+    feature_dim, num_edges = x.shape[1], edge_src.shape[0]
+    output = torch.empty(num_nodes, feature_dim, device=x.device, dtype=torch.float32)
+    call("fmd_cfconv_scatter_atomic", ptr(x), ptr(filter_out), _check_filt(filter_out),
+         ptr(edge_weight), ptr(edge_src), ptr(edge_dst), num_edges, num_nodes, feature_dim,
+         float(cutoff_upper), ptr(output), stream())
+    return output
+
+
+def _grad_edge(x, grad_output, filter_out, edge_weight, edge_src, edge_dst, cutoff_upper,
+               want_filt: bool, want_dist: bool, out_dtype):
+    num_edges, feature_dim = edge_src.shape[0], x.shape[1]
+    gfilt = torch.empty(num_edges, feature_dim, device=x.device, dtype=out_dtype) if want_filt else None
+    gdist = torch.empty(num_edges, device=x.device, dtype=torch.float32) if want_dist else None
+    if num_edges:
+        x, grad_output = _aligned(x), _aligned(grad_output)
+        filt = _aligned(filter_out) if filter_out is not None else None
+        call("fmd_cfconv_grad_edge", ptr(x), ptr(grad_output), ptr(filt),
+             1 if out_dtype == torch.float16 else 0, ptr(edge_weight), ptr(edge_src), ptr(edge_dst),
+             num_edges, feature_dim, float(cutoff_upper), ptr(gfilt), ptr(gdist), stream())
+    return gfilt, gdist
+
+
+def fused_grad_filter_out(x, grad_output, edge_weight, edge_src, edge_dst, cutoff_upper: float,
+                          out_dtype: torch.dtype = None) -> torch.Tensor:
+    """reference kernels/cfconv_kernels.py:261-337"""
+    assert x.is_cuda and x.is_contiguous()
+    assert grad_output.is_contiguous()
+    assert edge_weight.is_contiguous()
+    assert edge_src.is_contiguous()
+    assert edge_dst.is_contiguous()
+    if out_dtype is None:
+        out_dtype = x.dtype
+    gfilt, _ = _grad_edge(x, grad_output, None, edge_weight, edge_src, edge_dst, cutoff_upper,
+                          True, False, out_dtype)
+    return gfilt
+
+
+def _cfconv_backward(ctx, grad_output, x, filter_out, edge_weight, edge_src, edge_dst, src_ptr,
+                     src_perm):
+    """Shared backward of the two CFConv autograd functions (reference
+    kernels/csr_kernels.py:857-912, kernels/cfconv_kernels.py:361-415) + d/d(edge_weight)."""
+    grad_output = grad_output.contiguous()
+    grad_x = grad_filter_out = grad_edge_weight = None
+    if ctx.needs_input_grad[0]:
+        if src_ptr is not None and src_perm is not None:
+            grad_x = fused_src_csr_grad_x(grad_output, filter_out, edge_weight, edge_dst, src_ptr,
+                                          src_perm, ctx.num_nodes, ctx.cutoff_upper)
+        else:  # atomic scatter with the roles of src and dst exchanged
+            grad_x = fused_cutoff_gather_multiply_scatter(grad_output, filter_out, edge_weight,
+                                                          edge_dst, edge_src, ctx.num_nodes,
+                                                          ctx.cutoff_upper)
+    want_f, want_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    if want_f or want_d:
+        grad_filter_out, grad_edge_weight = _grad_edge(
+            x, grad_output, filter_out, edge_weight, edge_src, edge_dst, ctx.cutoff_upper, want_f,
+            want_d, ctx.filter_out_dtype)
+    return grad_x, grad_filter_out, grad_edge_weight
+
+
+class FusedCSRCFConvFunction(torch.autograd.Function):
+    """reference kernels/csr_kernels.py:818-912"""
+
+    @staticmethod
+    def forward(ctx, x, filter_out, edge_weight, edge_src, edge_dst, dst_ptr, csr_perm, num_nodes,
+                cutoff_upper, src_ptr, src_perm):
+        ctx.save_for_backward(x, filter_out, edge_weight, edge_src, edge_dst, dst_ptr, csr_perm,
+                              src_ptr, src_perm)
+        ctx.num_nodes, ctx.cutoff_upper = num_nodes, cutoff_upper
+        ctx.filter_out_dtype = filter_out.dtype
+        return fused_csr_cfconv(x, filter_out, edge_weight, edge_src, dst_ptr, csr_perm, num_nodes,
+                                cutoff_upper)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (x, filter_out, edge_weight, edge_src, edge_dst, _dst_ptr, _csr_perm, src_ptr,
+         src_perm) = ctx.saved_tensors
+        gx, gf, gd = _cfconv_backward(ctx, grad_output, x, filter_out, edge_weight, edge_src,
+                                      edge_dst, src_ptr, src_perm)
+        return gx, gf, gd, None, None, None, None, None, None, None, None
+
+
+def fused_csr_cfconv_autograd(x, filter_out, edge_weight, edge_src, edge_dst, dst_ptr, csr_perm,
+                              num_nodes: int, cutoff_upper: float, src_ptr=None, src_perm=None):
+    return FusedCSRCFConvFunction.apply(x, filter_out, edge_weight, edge_src, edge_dst, dst_ptr,
+                                        csr_perm, num_nodes, cutoff_upper, src_ptr, src_perm)
+
+
+class FusedCutoffGatherMultiplyScatterFunction(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:340-415"""
+
+    @staticmethod
+    def forward(ctx, x, filter_out, edge_weight, edge_src, edge_dst, num_nodes, cutoff_upper,
+                src_ptr, src_perm):
+        ctx.save_for_backward(x, filter_out, edge_weight, edge_src, edge_dst, src_ptr, src_perm)
+        ctx.num_nodes, ctx.cutoff_upper = num_nodes, cutoff_upper
+        ctx.filter_out_dtype = filter_out.dtype
+        return fused_cutoff_gather_multiply_scatter(x, filter_out, edge_weight, edge_src, edge_dst,
+                                                    num_nodes, cutoff_upper)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, filter_out, edge_weight, edge_src, edge_dst, src_ptr, src_perm = ctx.saved_tensors
+        gx, gf, gd = _cfconv_backward(ctx, grad_output, x, filter_out, edge_weight, edge_src,
+                                      edge_dst, src_ptr, src_perm)
+        return gx, gf, gd, None, None, None, None, None, None
+
+
+def fused_cutoff_gather_multiply_scatter_autograd(x, filter_out, edge_weight, edge_src, edge_dst,
+                                                  num_nodes: int, cutoff_upper: float,
+                                                  src_ptr=None, src_perm=None):
+    return FusedCutoffGatherMultiplyScatterFunction.apply(x, filter_out, edge_weight, edge_src,
+                                                          edge_dst, num_nodes, cutoff_upper,
+                                                          src_ptr, src_perm)
+
+
+# ==================================================================================================
+# fp32 GEMMs on the f32 MFMA (A7 and the node linears)
+# ==================================================================================================
+
+
+def gemm_f32(a, b, bias=None, aux=None, b_is_nk: bool = False, prologue: int = PRO_NONE,
+             epilogue: int = EPI_NONE) -> torch.Tensor:
+    """c = epi(pro(a[M,K]) @ B + bias); B is [K,N] (or [N,K] = nn.Linear.weight if b_is_nk)."""
+    _ffi.require_gpu(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32
+    assert a.is_contiguous() and b.is_contiguous()
+    m, k = a.shape
+    n = b.shape[0] if b_is_nk else b.shape[1]
+    assert (b.shape[1] if b_is_nk else b.shape[0]) == k, "dimension mismatch"
+    c = torch.empty((m, n), device=a.device, dtype=torch.float32)
+    call("fmd_gemm_f32", ptr(a), ptr(b), ptr(bias), ptr(aux), ptr(c), m, n, k, 1 if b_is_nk else 0,
+         prologue, epilogue, stream())
+    return c
+
+
+def fused_tanh_linear(x, weight, bias=None) -> torch.Tensor:
+    """Y = tanh(X) @ W + b, W is [K,N] (reference kernels/cfconv_kernels.py:1846-1898)."""
+    assert x.is_cuda and x.is_contiguous()
+    assert weight.is_cuda and weight.is_contiguous()
+    M, K = x.shape
+    K2, N = weight.shape
+    assert K == K2, f"Dimension mismatch: x has {K} columns but weight has {K2} rows"
+    return gemm_f32(x, weight, bias, prologue=PRO_TANH)
+
+
+class FusedTanhLinearFunction(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:1901-1941; grad_x runs as one MFMA kernel with the
+    (1 - tanh^2) factor in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = fused_tanh_linear(x, weight, bias)
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight, bias = ctx.saved_tensors
+        grad_x = grad_weight = grad_bias = None
+        tanh_x = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            tanh_x = torch.tanh(x)
+        if ctx.needs_input_grad[0]:
+            # (g @ W^T) * (1 - tanh(x)^2): W [K,N] read as the "[N',K']" operand of g[M,N]
+            grad_x = gemm_f32(grad_output.contiguous(), weight, aux=tanh_x, b_is_nk=True,
+                              epilogue=EPI_MUL_DTANH)
+        if ctx.needs_input_grad[1]:  # training only (reference K8); not on the simulation path
+            grad_weight = tanh_x.t() @ grad_output
+        if bias is not None and ctx.needs_input_grad[2]:
+            grad_bias = grad_output.sum(dim=0)
+        return grad_x, grad_weight, grad_bias
+
+
+def fused_tanh_linear_autograd(x, weight, bias=None) -> torch.Tensor:
+    return FusedTanhLinearFunction.apply(x, weight, bias)
+
+
+def fused_linear_tanh(x, weight, bias=None) -> torch.Tensor:
+    """Y = tanh(X @ W + b) in fp32 (reference kernels/cfconv_kernels.py:543-593)."""
+    assert x.is_cuda and x.is_contiguous()
+    assert weight.is_cuda and weight.is_contiguous()
+    M, K = x.shape
+    K2, N = weight.shape
+    assert K == K2, f"Dimension mismatch: x has {K} columns but weight has {K2} rows"
+    return gemm_f32(x, weight, bias, epilogue=EPI_TANH)
+
+
+class FusedLinearTanhFunction(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:596-627"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = fused_linear_tanh(x, weight, bias)
+        ctx.save_for_backward(x, weight, bias, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight, bias, y = ctx.saved_tensors
+        grad_z = grad_output * (1.0 - y * y)
+        grad_x = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_x = gemm_f32(grad_z.contiguous(), weight, b_is_nk=True)
+        if ctx.needs_input_grad[1]:
+            grad_weight = x.t() @ grad_z
+        if bias is not None and ctx.needs_input_grad[2]:
+            grad_bias = grad_z.sum(dim=0)
+        return grad_x, grad_weight, grad_bias
+
+
+def fused_linear_tanh_autograd(x, weight, bias=None) -> torch.Tensor:
+    return FusedLinearTanhFunction.apply(x, weight, bias)
+
+
+# ==================================================================================================
+# A4/A9  W16A16 GEMMs (fp16 storage, fp32 accumulate on MFMA)
+# ==================================================================================================
+
+
+def fused_linear_tanh_fp16(x, weight, bias=None) -> torch.Tensor:
+    """reference kernels/cfconv_kernels.py:723-758"""
+    assert x.dtype in (torch.float32, torch.float16), f"Input must be FP32 or FP16, got {x.dtype}"
+    assert weight.dtype == torch.float16, f"Weight must be FP16, got {weight.dtype}"
+    assert x.is_cuda and x.is_contiguous()
+    assert weight.is_cuda and weight.is_contiguous()
+    M, K = x.shape
+    K2, N = weight.shape
+    assert K == K2
+    y = torch.empty((M, N), device=x.device, dtype=torch.float16)
+    call("fmd_linear_tanh_f16", ptr(x), 1 if x.dtype == torch.float16 else 0, ptr(weight), ptr(bias),
+         ptr(y), M, N, K, stream())
+    return y
+
+
+def linear_fp16(x, weight, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """reference kernels/cfconv_kernels.py:835-892"""
+    assert x.dtype == torch.float16, f"Input must be FP16, got {x.dtype}"
+    assert weight.dtype == torch.float16, f"Weight must be FP16, got {weight.dtype}"
+    assert x.is_cuda and x.is_contiguous()
+    assert weight.is_cuda and weight.is_contiguous()
+    assert out_dtype in (torch.float32, torch.float16), "out_dtype must be FP32 or FP16"
+    M, K = x.shape
+    K2, N = weight.shape
+    assert K == K2
+    y = torch.empty((M, N), device=x.device, dtype=out_dtype)
+    call("fmd_linear_f16", ptr(x), ptr(weight), ptr(y), 1 if out_dtype == torch.float16 else 0, M, N,
+         K, stream())
+    return y
+
+
+def fused_tanh_backward_grad_x_v2(grad_out, y, weight_t) -> torch.Tensor:
+    """grad_x = f16(grad_out * (1 - y^2)) @ weight_t (reference kernels/cfconv_kernels.py:1038-1064)"""
+    M, K_out = grad_out.shape
+    K_out2, N = weight_t.shape
+    assert K_out == K_out2
+    assert grad_out.dtype in (torch.float16, torch.float32) and y.dtype == torch.float16
+    grad_x = torch.empty((M, N), device=grad_out.device, dtype=torch.float32)
+    call("fmd_tanh_bwd_grad_x_f16", ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0,
+         ptr(y), ptr(weight_t), ptr(grad_x), M, N, K_out, stream())
+    return grad_x
+
+
+def matmul_fp32_fp16_to_fp16_v2(a, b_t) -> torch.Tensor:
+    """c_f16 = f16(a_f32) @ b_t (reference kernels/cfconv_kernels.py:1211-1226)"""
+    M, K = a.shape
+    K2, N = b_t.shape
+    assert K == K2 and a.dtype == torch.float32 and b_t.dtype == torch.float16
+    c = torch.empty((M, N), device=a.device, dtype=torch.float16)
+    call("fmd_matmul_f32_f16_to_f16", ptr(a), ptr(b_t), ptr(c), M, N, K, stream())
+    return c
+
+
+class FusedLinearTanhFP16Function(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:1305-1361"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y_fp16 = fused_linear_tanh_fp16(x, weight, bias)
+        weight_t = weight.t().contiguous()
+        ctx.save_for_backward(x, weight_t, y_fp16)
+        ctx.has_bias = bias is not None
+        ctx.input_dtype = x.dtype
+        return y_fp16
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight_t, y_fp16 = ctx.saved_tensors
+        grad_output = grad_output.contiguous()
+        grad_x = grad_weight = grad_bias = None
+        if ctx.needs_input_grad[0]:
+            grad_x = fused_tanh_backward_grad_x_v2(grad_output, y_fp16, weight_t)
+            if ctx.input_dtype == torch.float16:
+                grad_x = grad_x.half()
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            grad_z = grad_output.float() * (1.0 - y_fp16.float() ** 2)  # training only (reference K8)
+            if ctx.needs_input_grad[1]:
+                grad_weight = (x.float().t() @ grad_z).half()
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                grad_bias = grad_z.sum(dim=0).half()
+        return grad_x, grad_weight, grad_bias
+
+
+class LinearFP16Function(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:1364-1399"""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = linear_fp16(x, weight)
+        ctx.save_for_backward(x, weight.t().contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight_t = ctx.saved_tensors
+        grad_x = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            grad_x = matmul_fp32_fp16_to_fp16_v2(grad_output.contiguous(), weight_t)
+        if ctx.needs_input_grad[1]:
+            grad_weight = (x.float().t() @ grad_output).half()
+        return grad_x, grad_weight
+
+
+class LinearFP16ToFP16Function(torch.autograd.Function):
+    """reference kernels/cfconv_kernels.py:1402-1434"""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        y = linear_fp16(x, weight, out_dtype=torch.float16)
+        ctx.save_for_backward(x, weight.t().contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight_t = ctx.saved_tensors
+        grad_x = grad_weight = None
+        if ctx.needs_input_grad[0]:
+            grad_x = matmul_fp32_fp16_to_fp16_v2(grad_output.float().contiguous(), weight_t)
+        if ctx.needs_input_grad[1]:
+            grad_weight = (x.float().t() @ grad_output.float()).half()
+        return grad_x, grad_weight
+
+
+def fused_linear_tanh_fp16_autograd(x, weight, bias=None):
+    return FusedLinearTanhFP16Function.apply(x, weight, bias)
+
+
+def linear_fp16_autograd(x, weight, out_dtype=torch.float32):
+    if out_dtype == torch.float32:
+        return LinearFP16Function.apply(x, weight)
+    return LinearFP16ToFP16Function.apply(x, weight)

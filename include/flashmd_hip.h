@@ -1,0 +1,169 @@
+/* flashmd_hip.h -- C ABI of the MI355X (gfx950) CGSchNet force-evaluation path.
+ *
+ * Drop-in boundary for the hot path of UNITES-Lab/flash-molecular-dynamics ("flashmd"): every
+ * entry point replaces one Triton-kernel host wrapper (or third-party native call) of the
+ * reference; the reference-side symbol each one stands in for is cited as
+ * <file>:<line> relative to /root/reference/src/flashmd.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory, sizes as int64_t, parameters as float/int; no torch types;
+ *   - tensors are contiguous row-major; index tensors are int64 (the reference's dtype);
+ *   - nothing is allocated inside: the caller passes outputs and (where named) a workspace;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - return 0 on success, a negative FMD_E* code otherwise (fmd_strerror gives the text);
+ *     no exceptions, no global state.
+ */
+#ifndef FLASHMD_HIP_H
+#define FLASHMD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMD_OK 0
+#define FMD_EINVAL (-1)     /* bad argument (null pointer, negative size, unsupported shape) */
+#define FMD_ELAUNCH (-2)    /* HIP reported a launch error */
+#define FMD_ECAPACITY (-3)  /* a fixed-capacity buffer was too small (reported by the *_status call) */
+#define FMD_EUNSUPPORTED (-4)
+
+const char* fmd_strerror(int code);
+/* ABI version of this library (bumped on any signature change). */
+int fmd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1  neighbour list: replaces torch_cluster.radius_graph(pos, rc, batch, flow="target_to_source",
+ *     loop=False) as called from neighbor_list/torch_impl.py:216-224.
+ *     Edges = ordered pairs (i,j), i!=j, same molecule, ((dx*dx+dy*dy)+dz*dz) < rc*rc (strict,
+ *     unfused fp32), sorted by centre i then neighbour j.  Two passes so the caller can size E:
+ *       fmd_radius_graph_count : deg[N] (int32) and row_ptr[N+1] (int64, exclusive scan of deg)
+ *       fmd_radius_graph_fill  : edge_src[E]=i, edge_dst[E]=j (int64) using row_ptr
+ *     mol_ptr[B+1] (int64): first bead of each molecule (data.ptr of the collated batch).
+ *     max_beads_per_mol: upper bound on beads in one molecule (sizes the grid; <= 0 = unknown).
+ * ------------------------------------------------------------------------------------------- */
+int fmd_radius_graph_count(const float* pos, const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                           int64_t max_beads_per_mol, float cutoff, int32_t* deg, int64_t* row_ptr,
+                           void* stream);
+int fmd_radius_graph_fill(const float* pos, const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                          int64_t max_beads_per_mol, float cutoff, const int64_t* row_ptr,
+                          int64_t* edge_src, int64_t* edge_dst, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2  fused distance + Gaussian RBF + cosine cutoff.
+ *     fwd replaces fused_distance_gaussian_rbf_cutoff   (kernels/cfconv_kernels.py:1578-1656)
+ *     bwd replaces FusedDistanceGaussianRBFCutoffFunction.backward (:1680-1735; that code raises
+ *         NameError in the reference -- the formula at :1696-1733 is the spec)
+ *     d[e] = |pos[dst]-pos[src]|, rbf[e,k] = exp(gamma (d-c_k)^2) * C(d), C = .5(cos(pi d/rc)+1)[d<rc]
+ *     bwd: grad_pos (zero-filled by the callee) += d(d, rbf)/d(pos) . (grad_d, grad_rbf);
+ *          grad_d / grad_rbf may be NULL (treated as zero).
+ * ------------------------------------------------------------------------------------------- */
+int fmd_distance_rbf_cutoff_fwd(const float* pos, const int64_t* edge_src, const int64_t* edge_dst,
+                                const float* centers, float gamma, float cutoff, int64_t n_edges,
+                                int64_t n_rbf, float* dist, float* rbf, void* stream);
+int fmd_distance_rbf_cutoff_bwd(const float* pos, const int64_t* edge_src, const int64_t* edge_dst,
+                                const float* centers, float gamma, float cutoff, int64_t n_edges,
+                                int64_t n_rbf, int64_t n_nodes, const float* dist,
+                                const float* grad_dist, const float* grad_rbf, float* grad_pos,
+                                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3  COO -> CSR bucket sort.  Replaces build_csr_index (kernels/csr_kernels.py:88-169) and
+ *     build_src_csr_index (:229-294): ptr[N+1] = [0, cumsum(bincount(keys))], perm[E] = original
+ *     edge ids grouped by key.  Output is the STABLE counting sort (ascending edge id inside a
+ *     segment) -- deterministic, and a member of the reference's (atomic-order) output set.
+ *     workspace: fmd_build_csr_workspace_bytes(N, E) bytes, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int64_t fmd_build_csr_workspace_bytes(int64_t n_nodes, int64_t n_edges);
+int fmd_build_csr(const int64_t* keys, int64_t n_edges, int64_t n_nodes, int64_t* ptr, int64_t* perm,
+                  void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A5/A6  CFConv message passing.  filt_is_f16: filter_out / grad_filter_out stored as fp16.
+ *   fmd_csr_cfconv_fwd       : fused_csr_cfconv          (kernels/csr_kernels.py:727-810)
+ *        out[n,:] = sum_{k in [ptr[n],ptr[n+1])} x[gather[perm[k]],:] * filt[perm[k],:] * C(d[perm[k]])
+ *        With (gather=edge_src, ptr/perm = dst-CSR) this is the forward; with (x=grad_out,
+ *        gather=edge_dst, ptr/perm = src-CSR) it is fused_src_csr_grad_x (:399-482).
+ *   fmd_cfconv_scatter_atomic: fused_cutoff_gather_multiply_scatter (kernels/cfconv_kernels.py:93-170)
+ *        out (zero-filled by the callee) [dst[e],:] += x[src[e],:] * filt[e,:] * C(d[e])  (float atomics)
+ *   fmd_cfconv_grad_edge     : fused_grad_filter_out     (kernels/cfconv_kernels.py:261-337)
+ *        gfilt[e,:] = x[src[e],:] * g[dst[e],:] * C(d[e])            (written in filt's dtype)
+ *        and, which the reference drops but its PyTorch path has (models/schnet.py:710-713):
+ *        gd[e] = C'(d[e]) * sum_f x[src[e],f] * filt[e,f] * g[dst[e],f]     (gd may be NULL)
+ *   fmd_csr_segment_reduce   : csr_segment_reduce        (kernels/csr_kernels.py:559-617)
+ * ------------------------------------------------------------------------------------------- */
+int fmd_csr_cfconv_fwd(const float* x, const void* filt, int filt_is_f16, const float* dist,
+                       const int64_t* gather, const int64_t* ptr, const int64_t* perm, int64_t n_nodes,
+                       int64_t n_feat, float cutoff, float* out, void* stream);
+int fmd_cfconv_scatter_atomic(const float* x, const void* filt, int filt_is_f16, const float* dist,
+                              const int64_t* edge_src, const int64_t* edge_dst, int64_t n_edges,
+                              int64_t n_nodes, int64_t n_feat, float cutoff, float* out, void* stream);
+int fmd_cfconv_grad_edge(const float* x, const float* grad_out, const void* filt, int filt_is_f16,
+                         const float* dist, const int64_t* edge_src, const int64_t* edge_dst,
+                         int64_t n_edges, int64_t n_feat, float cutoff, void* grad_filt,
+                         float* grad_dist, void* stream);
+int fmd_csr_segment_reduce(const float* msg, const int64_t* ptr, const int64_t* perm, int64_t n_nodes,
+                           int64_t n_feat, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A7 + node GEMMs (exact fp32 on v_mfma_f32_32x32x2_f32).
+ *   C[M,N] = epi( pro(A[M,K]) @ B + bias[N] )
+ *     b_is_nk   : 0 -> B is [K,N] row-major (the kernels' layout), 1 -> B is [N,K] (nn.Linear.weight)
+ *     prologue  : FMD_PRO_NONE | FMD_PRO_TANH (tanh applied to A)
+ *     epilogue  : FMD_EPI_NONE | FMD_EPI_TANH | FMD_EPI_MUL_DTANH (C *= 1 - aux^2, aux[M,N])
+ *   fused_tanh_linear  (kernels/cfconv_kernels.py:1846-1898)  = (b_is_nk=0, PRO_TANH, EPI_NONE)
+ *   its backward (:1920-1941) grad_x = (1 - tanh_x^2) * (g @ W^T) = (A=g, B=W [K,N] read as [N',K'],
+ *                                                                    b_is_nk=1, EPI_MUL_DTANH)
+ *   fused_linear_tanh  (:543-593)                              = (b_is_nk=0, PRO_NONE, EPI_TANH)
+ *   nn.Linear lin1/lin2 (models/schnet.py:644,719)             = (b_is_nk=1)
+ * ------------------------------------------------------------------------------------------- */
+#define FMD_PRO_NONE 0
+#define FMD_PRO_TANH 1
+#define FMD_EPI_NONE 0
+#define FMD_EPI_TANH 1
+#define FMD_EPI_MUL_DTANH 2
+int fmd_gemm_f32(const float* a, const float* b, const float* bias, const float* aux, float* c,
+                 int64_t m, int64_t n, int64_t k, int b_is_nk, int prologue, int epilogue, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4/A9  W16A16 GEMMs (fp16 storage, fp32 accumulate on v_mfma_f32_32x32x16_f16).
+ *   fmd_linear_tanh_f16   : fused_linear_tanh_fp16 (kernels/cfconv_kernels.py:723-758)
+ *        y_f16 = f16( tanh_c( f16(x) @ w_f16 + b_f16 ) ), tanh_c = (e^{2z}-1)/(e^{2z}+1), z clamped +-10 (:449-454)
+ *        x_is_f16: input dtype (fp32 inputs are rounded to fp16 on load, :701)
+ *   fmd_linear_f16        : linear_fp16 (:835-892)  y = x_f16 @ w_f16, stored fp32 (out_is_f16=0) or fp16
+ *   fmd_tanh_bwd_grad_x_f16 : fused_tanh_backward_grad_x_v2 (:1038-1064)
+ *        gx_f32[M,N] = f16( g * (1 - y^2) ) @ w_t_f16[K,N]       (g fp16 or fp32, y fp16)
+ *   fmd_matmul_f32_f16_to_f16 : matmul_fp32_fp16_to_fp16_v2 (:1211-1226)  c_f16 = f16(a_f32) @ b_f16
+ *   w / w_t / b are [K,N] row-major.
+ * ------------------------------------------------------------------------------------------- */
+int fmd_linear_tanh_f16(const void* x, int x_is_f16, const void* w, const void* bias, void* y,
+                        int64_t m, int64_t n, int64_t k, void* stream);
+int fmd_linear_f16(const void* x, const void* w, void* y, int out_is_f16, int64_t m, int64_t n,
+                   int64_t k, void* stream);
+int fmd_tanh_bwd_grad_x_f16(const void* g, int g_is_f16, const void* y, const void* w_t, float* gx,
+                            int64_t m, int64_t n, int64_t k, void* stream);
+int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m, int64_t n, int64_t k,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).
+ *   pre : v += .5 dt f/m ; x += .5 dt v ; v = vscale v + noisescale sqrt(1/(beta m)) * noise ; x += .5 dt v
+ *   post: v += .5 dt f/m
+ *   noise[N,3] is supplied by the caller (torch's generator, langevin.py:146), beta per node.
+ * Row (e): parallel-tempering swap of accepted pairs (simulation/parallel_tempering.py:415-481):
+ *   for each accepted pair p: x[a] <-> x[b], v[a] = v[b]*sqrt(beta_a/beta_b), v[b] = v[a]*sqrt(beta_b/beta_a)
+ *   (molecule a/b = mol_a[p]/mol_b[p], n_atoms beads each, in place).
+ * ------------------------------------------------------------------------------------------- */
+int fmd_langevin_pre(float* x, float* v, const float* f, const float* masses, const float* beta_node,
+                     const float* noise, int64_t n_nodes, float dt, float vscale, float noisescale,
+                     void* stream);
+int fmd_langevin_post(float* v, const float* f, const float* masses, int64_t n_nodes, float dt,
+                      void* stream);
+int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* mol_b,
+                      const uint8_t* accept, const float* beta_mol, int64_t n_pairs, int64_t n_atoms,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHMD_HIP_H */

@@ -1,0 +1,86 @@
+"""GPU parity tests, model granularity: energies and forces of the whole path against the reference's
+own fp64 vectors (tests/golden, produced by the reference's StandardSchNet + GradientsOut) and the CPU
+oracle.  Tolerance of the path (BASELINE.json north_star): 1e-4 relative; fp32 lands near 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import schnet_oracle as so
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def params(golden_dir):
+    return so.params_from_npz(os.path.join(golden_dir, "weights_L3_R50.npz"))
+
+
+def _relerr(e, f, e_ref, f_ref):
+    e_ref, f_ref = np.asarray(e_ref, np.float64), np.asarray(f_ref, np.float64)
+    re = float(np.abs(e.double().cpu().numpy() - e_ref).max() / np.abs(e_ref).max())
+    rf = float(np.linalg.norm(f.double().cpu().numpy() - f_ref) / np.linalg.norm(f_ref))
+    return re, rf
+
+
+def _run(S, p, pos, types, ptr, engine: bool, w16a16: bool = False, A: int = 0):
+    S.USE_FUSED_ENGINE = engine
+    model = S.model_from_params(p).to(DEV)
+    if w16a16:
+        from flashmd_amd.gptq import apply_gptq_w16a16_to_model, validate_gptq_w16a16
+
+        apply_gptq_w16a16_to_model(model)
+        validate_gptq_w16a16(model)
+    model = S.GradientsOut(model).eval()
+    data = model(S.Batch(pos.to(DEV), types.to(DEV), ptr.to(DEV), max_beads_per_mol=A))
+    return data.out["SchNet"]["energy"].detach(), data.out["SchNet"]["forces"].detach()
+
+
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
+def test_operator_path_vs_reference_vectors(params, golden_dir, case):
+    import flashmd_amd.schnet as S
+
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
+    e, f = _run(S, params, pos, types, ptr, engine=False)
+    re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+    print(f"{case}: operator path energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4
+    assert re < 2e-5 and rf < 2e-5  # where fp32 actually lands
+
+
+def test_operator_path_w16a16_vs_w16a16_oracle(params, golden_dir):
+    """BASELINE config 3.  The W16A16 oracle restates the reference's rounding points;
+    the reference's fp16 Triton path cannot run in the build container, so this config is
+    'parity unpinned' beyond that restatement.  Tolerance 2e-3 on forces (fp16 storage: the order of
+    fp32 accumulation moves results across fp16 rounding boundaries), and the deviation from the
+    fp32 reference is reported."""
+    import flashmd_amd.schnet as S
+
+    z = np.load(os.path.join(golden_dir, "case_small_3x37.npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
+    e, f = _run(S, params, pos, types, ptr, engine=False, w16a16=True)
+    e_o, f_o = so.schnet_energy_forces(params, pos, types, ptr, w16a16=True)
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    re32, rf32 = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+    print(f"w16a16: vs w16a16 oracle energy {re:.2e} forces {rf:.2e}; vs fp64 reference {re32:.2e} {rf32:.2e}")
+    assert re < 2e-3 and rf < 2e-3
+    assert rf32 < 5e-2
+
+
+def test_operator_path_deterministic_csr(params):
+    """CSR segment reductions have no float atomics: two CFConv evaluations are bit-identical."""
+    import flashmd_amd.kernels as K
+
+    pos, types, ptr = so.synth_batch(2, 269, 5.0)
+    src, dst = so.radius_graph(pos, ptr, 5.0)
+    n = pos.shape[0]
+    g = torch.Generator().manual_seed(0)
+    x, filt = torch.randn(n, 128, generator=g).to(DEV), torch.randn(src.numel(), 128, generator=g).to(DEV)
+    d = so.compute_distances(pos, src, dst).to(DEV)
+    dst_ptr, perm = K.build_csr_index(dst.to(DEV), n)
+    a = K.fused_csr_cfconv(x, filt, d, src.to(DEV), dst_ptr, perm, n, 5.0)
+    b = K.fused_csr_cfconv(x, filt, d, src.to(DEV), dst_ptr, perm, n, 5.0)
+    assert torch.equal(a, b)
