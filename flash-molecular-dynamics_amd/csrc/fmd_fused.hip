@@ -24,7 +24,7 @@ namespace {
 constexpr int F = 128;            // hidden = filters
 constexpr int LDA = 132;          // LDS row stride (floats) of a 32 x 128 operand tile
 constexpr int TILE_FLOATS = 32 * LDA;
-constexpr int MAX_LDS_ROWS = 288; // beads per molecule whose aggregate fits LDS next to the tile buffer
+constexpr int MAX_LDS_ROWS = 286; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
 constexpr int SLICE = 4 * 64 * 64;  // floats of one packed 128x128 operand ([wave][k-step][lane])
 constexpr int P0_FLOATS = 4 * 32 * 64;
 
@@ -119,6 +119,14 @@ __device__ __forceinline__ f32x16 gemm_rows_packed(const float* lds_a, const flo
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], bp[(4 * s4 + q) * 64], acc, 0, 0, 0);
   }
   return acc;
+}
+
+// same, but the operand pointer is made opaque so the loads stay inside the caller's tile loop
+// (hoisting eight 64-register operands out of the output-network loop would spill)
+__device__ __forceinline__ f32x16 gemm_rows_streamed(const float* lds_a, const float* pk, int w,
+                                                     int lane) {
+  asm volatile("" : "+s"(pk));
+  return gemm_rows_packed(lds_a, pk, w, lane);
 }
 
 __device__ __forceinline__ void tile_to_lds(float* buf, const f32x16& v, int w, int lane) {
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     float* nxt = bufB;
 #pragma unroll
     for (int k = 0; k < NUM_OUT - 1; ++k) {
-      hk[k] = gemm_rows_packed(cur, a.po[k], w, lane);
+      hk[k] = gemm_rows_streamed(cur, a.po[k], w, lane);
       const float bk = a.bo[k][col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh(hk[k][r] + bk);
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    const f32x16 e = gemm_rows_packed(cur, a.po[NUM_OUT - 1], w, lane);
+    const f32x16 e = gemm_rows_streamed(cur, a.po[NUM_OUT - 1], w, lane);
     if (col == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -599,14 +607,14 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     { float* tmp = cur; cur = nxt; nxt = tmp; }
 #pragma unroll
     for (int k = NUM_OUT - 1; k >= 1; --k) {
-      g = gemm_rows_packed(cur, a.pot[k], w, lane);
+      g = gemm_rows_streamed(cur, a.pot[k], w, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
       tile_to_lds(nxt, g, w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    g = gemm_rows_packed(cur, a.pot[0], w, lane);
+    g = gemm_rows_streamed(cur, a.pot[0], w, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);

@@ -35,10 +35,36 @@ SIGNATURES = {
     "fmd_linear_f16": (I32, [P, P, P, I32, I64, I64, I64, P]),
     "fmd_tanh_bwd_grad_x_f16": (I32, [P, I32, P, P, P, I64, I64, I64, P]),
     "fmd_matmul_f32_f16_to_f16": (I32, [P, P, P, I64, I64, I64, P]),
+    "fmd_schnet_pack_bytes": (I64, [P]),
+    "fmd_schnet_pack": (I32, [P, P, P, P]),
+    "fmd_schnet_workspace_bytes": (I64, [P, I64, I64, I64]),
+    "fmd_schnet_energy_forces": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P]),
     "fmd_langevin_pre": (I32, [P, P, P, P, P, P, I64, F32, F32, F32, P]),
     "fmd_langevin_post": (I32, [P, P, P, I64, F32, P]),
     "fmd_pt_swap_local": (I32, [P, P, P, P, P, P, I64, I64, P]),
 }
+
+
+
+class SchnetDesc(ctypes.Structure):
+    """fmd_schnet_desc (include/flashmd_hip.h)"""
+    _fields_ = [("hidden", ctypes.c_int32), ("num_rbf", ctypes.c_int32), ("num_blocks", ctypes.c_int32),
+                ("num_out", ctypes.c_int32), ("out_width", ctypes.c_int32 * 4),
+                ("embedding_size", ctypes.c_int32), ("precision", ctypes.c_int32),
+                ("n_split", ctypes.c_int32), ("cutoff", ctypes.c_float), ("gamma", ctypes.c_float)]
+
+
+class SchnetBlockWeights(ctypes.Structure):
+    """fmd_schnet_block_weights: host pointers, nn.Linear [out,in] layout"""
+    _fields_ = [(n, c_void_p) for n in ("lin1_w", "f0_w", "f0_b", "f1_w", "lin2_w", "lin2_b", "lin_w",
+                                        "lin_b")]
+
+
+class SchnetWeights(ctypes.Structure):
+    """fmd_schnet_weights"""
+    _fields_ = [("embedding", c_void_p), ("blocks", ctypes.POINTER(SchnetBlockWeights)),
+                ("out_w", c_void_p * 4), ("out_b", c_void_p * 4)]
+
 
 _lib = None
 

@@ -1,11 +1,155 @@
-"""Fused whole-path engine (energy + forces of a batch in one HIP pipeline).  Placeholder until the
-fused kernels land: qualifies no model, so GradientsOut takes the operator path."""
+"""Fused whole-path engine: energy[B] and forces[N,3] of a batch in one HIP pipeline with no
+[E,F] tensor in HBM (csrc/fmd_fused.hip behind fmd_schnet_energy_forces).
+
+Replaces, for qualifying models, what the reference does per timestep in SchNet.forward +
+GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model
+qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
+<= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
+tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights, and no
+molecule larger than 286 beads (its aggregate must fit the 160 KB LDS).  Anything else returns
+None here and GradientsOut uses the operator path.
+"""
 from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _ffi
+from ._ffi import call, ptr, stream
+
+MAX_BEADS = 286
+PREC_F32 = 0
+
+
+def _linears(mlp):
+    return [m for m in mlp.layers if isinstance(m, torch.nn.Linear)]
+
+
+class FusedSchNetEngine:
+    """Packed weights + workspace for one model on one device."""
+
+    def __init__(self, model, n_split: int = 0):
+        from .schnet import CosineCutoff, GaussianBasis
+
+        rbf = model.rbf_layer
+        blocks = list(model.interaction_blocks)
+        if not isinstance(rbf, GaussianBasis) or not isinstance(rbf.cutoff, CosineCutoff):
+            raise ValueError("fused engine: needs GaussianBasis with CosineCutoff")
+        if rbf.cutoff.cutoff_lower != 0 or rbf.num_rbf > 64 or rbf.num_rbf < 2:
+            raise ValueError("fused engine: cutoff_lower must be 0 and 2 <= num_rbf <= 64")
+        hidden = model.embedding_layer.embedding_dim
+        for blk in blocks:
+            cut = blk.conv.cutoff
+            if not isinstance(cut, CosineCutoff) or cut.cutoff_lower != 0 \
+                    or cut.cutoff_upper != rbf.cutoff.cutoff_upper:
+                raise ValueError("fused engine: CFConv cutoff must equal the basis cutoff")
+            if not isinstance(blk.activation, torch.nn.Tanh) or not hasattr(blk.conv.filter_network, "layers"):
+                raise ValueError("fused engine: tanh activation and an fp32 MLP filter network required")
+            fl = _linears(blk.conv.filter_network)
+            if len(fl) != 2 or fl[0].out_features != 128 or fl[1].out_features != 128 or fl[1].bias is not None:
+                raise ValueError("fused engine: filter network must be Linear(R,128)+tanh+Linear(128,128,no bias)")
+        if hidden != 128 or not hasattr(model.output_network, "layers"):
+            raise ValueError("fused engine: hidden = filters = 128 and an fp32 MLP output network required")
+        outs = _linears(model.output_network)
+        if len(outs) not in (2, 3) or outs[-1].out_features != 1 or outs[-1].bias is not None \
+                or any(o.out_features > 128 for o in outs):
+            raise ValueError("fused engine: output MLP must have 2-3 linears, widths <= 128, last -> 1 without bias")
+
+        self.device = model.embedding_layer.weight.device
+        self.cutoff = float(rbf.cutoff.cutoff_upper)
+        d = _ffi.SchnetDesc()
+        d.hidden, d.num_rbf, d.num_blocks, d.num_out = 128, rbf.num_rbf, len(blocks), len(outs)
+        for k in range(4):
+            d.out_width[k] = outs[k].out_features if k < len(outs) else 0
+        d.embedding_size = model.embedding_layer.num_embeddings
+        d.precision, d.n_split = PREC_F32, int(n_split)
+        d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
+        self.desc = d
+
+        # host copies of the weights (fp32, contiguous) -> packed register-order buffer -> device
+        keep = []
+
+        def host(t):
+            h = t.detach().to("cpu", torch.float32).contiguous()
+            keep.append(h)
+            return ctypes.c_void_p(h.data_ptr())
+
+        bw = (_ffi.SchnetBlockWeights * len(blocks))()
+        for l, blk in enumerate(blocks):
+            fl = _linears(blk.conv.filter_network)
+            bw[l].lin1_w = host(blk.conv.lin1.weight)
+            bw[l].f0_w, bw[l].f0_b, bw[l].f1_w = host(fl[0].weight), host(fl[0].bias), host(fl[1].weight)
+            bw[l].lin2_w, bw[l].lin2_b = host(blk.conv.lin2.weight), host(blk.conv.lin2.bias)
+            bw[l].lin_w, bw[l].lin_b = host(blk.lin.weight), host(blk.lin.bias)
+        w = _ffi.SchnetWeights()
+        w.embedding = host(model.embedding_layer.weight)
+        w.blocks = ctypes.cast(bw, ctypes.POINTER(_ffi.SchnetBlockWeights))
+        for k, o in enumerate(outs):
+            w.out_w[k] = host(o.weight)
+            w.out_b[k] = host(o.bias) if o.bias is not None else None
+        centers = host(rbf.offset)
+        nbytes = _ffi.lib().fmd_schnet_pack_bytes(ctypes.byref(d))
+        if nbytes <= 0:
+            raise ValueError("fused engine: model rejected by fmd_schnet_pack_bytes")
+        packed = torch.empty(nbytes // 4, dtype=torch.float32)
+        call("fmd_schnet_pack", ctypes.byref(d), ctypes.byref(w), centers, ctypes.c_void_p(packed.data_ptr()))
+        self.packed = packed.to(self.device)
+        self._ws = None
+        self._ws_key = None
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+
+    def _workspace(self, n_mol, n_nodes, cap):
+        key = (n_mol, n_nodes, cap)
+        if self._ws_key != key:
+            nbytes = _ffi.lib().fmd_schnet_workspace_bytes(ctypes.byref(self.desc), n_mol, n_nodes, cap)
+            if nbytes <= 0:
+                raise RuntimeError("fmd_schnet_workspace_bytes failed")
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        off = (-self._ws.data_ptr()) % 256
+        return ctypes.c_void_p(self._ws.data_ptr() + off)
+
+    def energy_forces(self, pos, atom_types, mol_ptr, max_beads_per_mol: int = 0):
+        """energy[B] f32, forces[N,3] f32 of the batch; everything enqueued on the current stream."""
+        _ffi.require_gpu(pos, atom_types, mol_ptr)
+        pos = pos.detach()
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and atom_types.dtype == torch.int64
+        n_nodes, n_mol = pos.shape[0], mol_ptr.numel() - 1
+        if max_beads_per_mol <= 0:  # one host sync, only when the caller did not say
+            max_beads_per_mol = int((mol_ptr[1:] - mol_ptr[:-1]).max().item()) if n_mol else 1
+        if max_beads_per_mol > MAX_BEADS:
+            raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {MAX_BEADS}")
+        cap = max(32, (max_beads_per_mol * (max_beads_per_mol - 1) // 2 + 31) // 32 * 32)
+        energy = torch.empty(n_mol, dtype=torch.float32, device=pos.device)
+        forces = torch.empty(n_nodes, 3, dtype=torch.float32, device=pos.device)
+        call("fmd_schnet_energy_forces", ctypes.byref(self.desc), ptr(self.packed), ptr(pos),
+             ptr(atom_types), ptr(mol_ptr), n_mol, n_nodes, max_beads_per_mol, cap, ptr(energy),
+             ptr(forces), self._workspace(n_mol, n_nodes, cap), ptr(self.status), stream())
+        return energy, forces
 
 
 def maybe_engine(model, data):
+    """Engine for ``model`` if it qualifies (cached on the model), else None (operator path)."""
     if not data.pos.is_cuda:
         raise RuntimeError(
             "flashmd_amd: the HIP gates are on but the batch is on the CPU. There is no CPU fallback "
             "for the optimized path; run with --disable_optim (all MLCG_USE_* = 0).")
-    return None
+    eng = getattr(model, "_engine", None)
+    if eng is False:
+        return None
+    if eng is None:
+        try:
+            eng = FusedSchNetEngine(model)
+        except ValueError:
+            model._engine = False
+            return None
+        model._engine = eng
+    mb = int(getattr(data, "max_beads_per_mol", 0))
+    if mb <= 0:
+        ptr_ = data.ptr
+        mb = int((ptr_[1:] - ptr_[:-1]).max().item())
+        data.max_beads_per_mol = mb
+    if mb > MAX_BEADS:
+        return None
+    return eng

@@ -146,6 +146,67 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Whole-path engine: energy[B] and forces[N,3] of a batch in one call, no [E,F] tensor in HBM.
+ * Replaces SchNet.forward (models/schnet.py:178-369) + GradientsOut.forward
+ * (models/gradients.py:226-290) for StandardSchNet models (Gaussian basis, cosine cutoff with
+ * lower bound 0, tanh, hidden = filters = 128).
+ *   Weights are packed once by fmd_schnet_pack_bytes / fmd_schnet_pack (device buffer).
+ *   precision: FMD_PREC_F32 (exact fp32 MFMA); FMD_PREC_W16A16 is reserved (returns FMD_EINVAL).
+ * ------------------------------------------------------------------------------------------- */
+#define FMD_PREC_F32 0
+#define FMD_PREC_W16A16 1
+
+typedef struct fmd_schnet_desc {
+  int32_t hidden;        /* = num_filters = 128 */
+  int32_t num_rbf;       /* R (<= 64) */
+  int32_t num_blocks;    /* L */
+  int32_t num_out;       /* number of output-network linears (2 or 3) */
+  int32_t out_width[4];  /* widths after each output linear, last = 1 */
+  int32_t embedding_size;
+  int32_t precision;
+  int32_t n_split;       /* workgroups per molecule in the pair kernels; 0 = auto (CUs / n_mol, 1..8) */
+  float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
+  float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
+} fmd_schnet_desc;
+
+/* Host pointers to the reference's parameter tensors (fp32, nn.Linear [out,in] layout). */
+typedef struct fmd_schnet_block_weights {
+  const float* lin1_w;            /* [F,H]  CFConv.lin1 (no bias), models/schnet.py:584 */
+  const float* f0_w; const float* f0_b; /* [F,R],[F] filter MLP layer 0, models/schnet.py:813-817 */
+  const float* f1_w;              /* [F,F]  filter MLP layer 1 (no bias) */
+  const float* lin2_w; const float* lin2_b; /* [H,F],[H]  CFConv.lin2, :585 */
+  const float* lin_w; const float* lin_b;   /* [H,H],[H]  InteractionBlock.lin, :479 */
+} fmd_schnet_block_weights;
+
+typedef struct fmd_schnet_weights {
+  const float* embedding;               /* [embedding_size, H] */
+  const fmd_schnet_block_weights* blocks; /* [num_blocks] */
+  const float* out_w[4];                /* [out_width[k], in] */
+  const float* out_b[4];                /* NULL when the layer has no bias */
+} fmd_schnet_weights;
+
+int64_t fmd_schnet_pack_bytes(const fmd_schnet_desc* desc);
+/* Packs HOST weight tensors (and the num_rbf RBF centres, GaussianBasis.offset) into `packed_host`
+ * (pack_bytes bytes) in the per-lane register order the kernels load; the caller copies that buffer
+ * to the device once. */
+int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_weights* w, const float* centers,
+                    void* packed_host);
+
+int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, int64_t n_nodes,
+                                   int64_t max_pairs_per_mol);
+/* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY, [1] = max pairs seen in one molecule,
+ * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
+/* max_beads_per_mol: upper bound on beads of one molecule (<= 286: the per-molecule aggregate lives
+ * in LDS; larger molecules return FMD_EUNSUPPORTED and take the operator path).
+ * max_pairs_per_mol: capacity of the per-molecule pair list; A(A-1)/2 can never overflow.
+ * workspace: fmd_schnet_workspace_bytes bytes, 256-byte aligned. */
+int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
+                             const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
+                             int64_t n_nodes, int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                             float* energy, float* forces, void* workspace, int32_t* status,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).
  *   pre : v += .5 dt f/m ; x += .5 dt v ; v = vscale v + noisescale sqrt(1/(beta m)) * noise ; x += .5 dt v
  *   post: v += .5 dt f/m

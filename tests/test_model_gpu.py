@@ -84,3 +84,63 @@ def test_operator_path_deterministic_csr(params):
     a = K.fused_csr_cfconv(x, filt, d, src.to(DEV), dst_ptr, perm, n, 5.0)
     b = K.fused_csr_cfconv(x, filt, d, src.to(DEV), dst_ptr, perm, n, 5.0)
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused engine (fmd_schnet_energy_forces): same vectors, same budget
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
+def test_fused_engine_vs_reference_vectors(params, golden_dir, case):
+    import flashmd_amd.schnet as S
+
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
+    e, f = _run(S, params, pos, types, ptr, engine=True)
+    re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+    print(f"{case}: fused engine energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4
+    assert re < 2e-5 and rf < 2e-5
+
+
+def test_fused_engine_is_the_path_taken_and_deterministic(params):
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    S.USE_FUSED_ENGINE = True
+    pos, types, ptr = so.synth_batch(8, 269, 5.0)
+    model = S.model_from_params(params).to(DEV)
+    eng = engine.FusedSchNetEngine(model)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    e1, f1 = eng.energy_forces(P, T, Q, 269)
+    e2, f2 = eng.energy_forces(P, T, Q, 269)
+    assert torch.equal(e1, e2) and torch.equal(f1, f2)  # no unordered float atomics anywhere
+    st = eng.status.cpu().tolist()
+    src, _ = so.radius_graph(pos, ptr, 5.0)
+    assert st[0] == 0 and st[2] == src.numel() // 2  # pair count == half the directed edge count
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    re, rf = _relerr(e1, f1, e_o.numpy(), f_o.numpy())
+    print(f"8x269 fused engine vs fp64 oracle: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4
+    # n_split must not change the physics (different partial-sum grouping only)
+    for ns in (1, 3):
+        eng2 = engine.FusedSchNetEngine(model, n_split=ns)
+        e3, f3 = eng2.energy_forces(P, T, Q, 269)
+        assert _relerr(e3, f3, e_o.numpy(), f_o.numpy())[1] < 1e-4
+
+
+def test_fused_engine_other_hyperparameters():
+    """R = 64 / L = 2 / output widths [32, 16] / 2-linear output net / non-zero biases."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    for kw in (dict(num_rbf=64, num_interactions=2, out_widths=(32, 16)),
+               dict(num_rbf=20, num_interactions=1, out_widths=(64,)),
+               dict(num_rbf=33, num_interactions=2, out_widths=(128, 128))):
+        p = so.make_params(seed=3, bias_scale=0.1, **kw)
+        pos, types, ptr = so.synth_batch(3, 50, 5.0)
+        e_o, f_o = so.schnet_energy_forces(so.params_to(p, torch.float64), pos.double(), types, ptr)
+        eng = engine.FusedSchNetEngine(S.model_from_params(p).to(DEV))
+        e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+        re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+        print(f"{kw}: energy {re:.2e} forces {rf:.2e}")
+        assert re < 2e-5 and rf < 2e-5
