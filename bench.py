@@ -1,0 +1,218 @@
+"""Benchmark of the hot path: timestep*mol/s of CGSchNet Langevin dynamics on synthetic 1ENH-shaped
+batches (BASELINE.json metric), one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A step is one BAOAB Langevin timestep of the rank's batch: fused elementwise half, the fused HIP
+force engine (neighbour pairs -> SchNet energy -> forces), second half-kick.  Inputs are resident in
+HBM before the timed region.  Replicas shard across ranks with no collective in the data path (weak
+scaling: every rank owns --batch molecules).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "flash-molecular-dynamics_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PUBLISHED_BASELINE = 2861.0  # timestep*mol/s, reference README.md:76-81 (1ENH, batch 128, RTX PRO 6000)
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters (fp32 matrix, dense)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="molecules per GPU")
+    ap.add_argument("--beads", type=int, default=269)
+    ap.add_argument("--num-rbf", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+class HipEvents:
+    """Timing events created through the HIP runtime (recorded by the C ABI on torch's stream)."""
+
+    def __init__(self, n):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ev = (ctypes.c_void_p * n)()
+        for i in range(n):
+            h = ctypes.c_void_p()
+            assert self.hip.hipEventCreate(ctypes.byref(h)) == 0
+            self.ev[i] = h
+
+    def elapsed_ms(self, i, j):
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(self.ev[i]), ctypes.c_void_p(self.ev[j]))
+        assert rc == 0, rc
+        return ms.value
+
+
+def cpu_baseline(model, args, seconds):
+    """The CPU oracle (a port of the reference's --disable_optim PyTorch path) timed on this node's
+    host cores on a bounded sample of the same workload (same throughput definition)."""
+    from oracle import schnet_oracle as so
+    from flashmd_amd import synthetic
+
+    p = {"hidden": 128, "filters": 128, "num_rbf": args.num_rbf, "cutoff": 5.0,
+         "emb": model.embedding_layer.weight.detach().cpu(), "blocks": [], "out": []}
+    for blk in model.interaction_blocks:
+        fl = [m for m in blk.conv.filter_network.layers if isinstance(m, torch.nn.Linear)]
+        p["blocks"].append({k: v.detach().cpu() for k, v in dict(
+            lin1_w=blk.conv.lin1.weight, f0_w=fl[0].weight, f0_b=fl[0].bias, f1_w=fl[1].weight,
+            lin2_w=blk.conv.lin2.weight, lin2_b=blk.conv.lin2.bias, lin_w=blk.lin.weight,
+            lin_b=blk.lin.bias).items()})
+    for m in model.output_network.layers:
+        if isinstance(m, torch.nn.Linear):
+            p["out"].append({"w": m.weight.detach().cpu(),
+                             "b": None if m.bias is None else m.bias.detach().cpu()})
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    n_mol = 8
+    pos, types, ptr, masses = synthetic.batch(n_mol, args.beads, 5.0)
+    so.schnet_energy_forces(p, pos, types, ptr)  # warm-up
+    t0 = time.perf_counter()
+    so.schnet_energy_forces(p, pos, types, ptr)
+    one = time.perf_counter() - t0
+    reps = int(max(3, min(40, seconds / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        e, f = so.schnet_energy_forces(p, pos, types, ptr)
+        v = so.langevin_baoab_post(f, f, masses, 0.004)  # integrator cost is negligible; keep a token of it
+    dt = time.perf_counter() - t0
+    return {"value": reps * n_mol / dt, "unit": "timestep*mol/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{reps} force evaluations of {n_mol} molecules x {args.beads} beads "
+                      f"(oracle/schnet_oracle.py, fp32, {dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, simulate, synthetic
+
+    torch.manual_seed(0)
+    rc = 5.0
+    model = S.StandardSchNet(S.GaussianBasis(S.CosineCutoff(0.0, rc), args.num_rbf), S.CosineCutoff(0.0, rc),
+                             [128, 64], num_interactions=args.blocks)
+    with torch.no_grad():  # the reference zero-initialises biases; use small non-zero ones
+        for n_, prm in model.named_parameters():
+            if n_.endswith("bias"):
+                prm.uniform_(-0.1, 0.1)
+    model = model.to(dev).eval()
+    eng = engine.FusedSchNetEngine(model)
+    names = eng.kernel_names()
+
+    # every rank owns its own molecules (different seeds per rank): embarrassingly parallel shards
+    pos, types, ptr, masses = synthetic.batch(args.batch, args.beads, rc, first_seed=1000 + rank * args.batch)
+    pos, types, ptr, masses = pos.to(dev), types.to(dev), ptr.to(dev), masses.to(dev)
+    beta = torch.full((args.batch,), 1.67, device=dev)  # reference examples/langevin.yaml:20
+
+    nk = len(names)
+    events = HipEvents(2 * nk * args.steps)
+    step_no = {"i": -1}
+
+    def force_fn(x):
+        i = step_no["i"]
+        if 0 <= i < args.steps:
+            ev = (ctypes.c_void_p * (2 * nk)).from_buffer(events.ev, i * 2 * nk * ctypes.sizeof(ctypes.c_void_p))
+            return eng.energy_forces(x, types, ptr, args.beads, events=ev)
+        return eng.energy_forces(x, types, ptr, args.beads)
+
+    sim = simulate.LangevinSimulation(force_fn, pos, masses, beta, args.beads, dt=0.004, friction=1.0)
+    for _ in range(args.warmup):
+        sim.timestep()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_no["i"] = i
+        sim.timestep()
+    step_no["i"] = -1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(sim.x).all() and torch.isfinite(sim.f).all(), "simulation diverged"
+    st = eng.status.cpu().tolist()
+    assert st[0] == 0, "pair capacity overflow"
+    n_pairs = st[2]
+
+    if rank == 0:
+        # per-kernel device time from the events recorded on the launch stream
+        per = {}
+        for k, name in enumerate(names):
+            ms = [events.elapsed_ms((i * nk + k) * 2, (i * nk + k) * 2 + 1) for i in range(args.steps)]
+            per.setdefault(name, []).extend(ms)
+        launches = {n: len(v) / args.steps for n, v in per.items()}
+        avg_ms = {n: sum(v) / len(v) for n, v in per.items()}
+        dom = max(avg_ms, key=lambda n: avg_ms[n] * launches[n])
+        n_edges = 2 * n_pairs  # directed edges of the reference's graph
+        F, R = 128, args.num_rbf
+        # algorithmic FLOPs per launch: filter nets of one block, forward
+        # (edge_fwd) or input-gradient backward (edge_bwd): 2*E*F*(R+F) each
+        alg_flops = 2.0 * n_edges * F * (R + F)
+        achieved = alg_flops / (avg_ms[dom] * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        value = args.steps * args.batch * world / elapsed
+        line = {
+            "metric": "timestep*mol/s, CGSchNet 1ENH batch=128",
+            "value": value, "unit": "timestep*mol/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": value / PUBLISHED_BASELINE,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CGSchNet 1ENH batch=128 Langevin fp32 (BASELINE configs[1])",
+                       "molecules_per_gpu": args.batch, "beads_per_molecule": args.beads,
+                       "directed_edges_per_gpu": n_edges, "num_rbf": R, "interaction_blocks": args.blocks,
+                       "hidden": 128, "output_widths": [128, 64, 1], "cutoff": rc, "dt": 0.004,
+                       "sharding": f"replica-sharded x{world}, no collective in the force path",
+                       "baseline_note": "2861 = reference README (W16A16, real 1ENH, RTX PRO 6000)"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": avg_ms[dom],
+                         "launches_per_step": launches[dom]},
+            "kernel_ms_per_launch": {n: round(v, 4) for n, v in avg_ms.items()},
+            "kernel_ms_per_step": {n: round(avg_ms[n] * launches[n], 4) for n in avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, args, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

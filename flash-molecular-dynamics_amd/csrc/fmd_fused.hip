@@ -879,12 +879,11 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
   return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split).total + 256;
 }
 
-extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev,
-                                        const float* pos, const int64_t* atom_types,
-                                        const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
-                                        int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
-                                        float* energy, float* forces, void* workspace,
-                                        int32_t* status, void* stream) {
+static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
+                      const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
+                      int64_t n_nodes, int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                      float* energy, float* forces, void* workspace, int32_t* status, void* stream,
+                      hipEvent_t* ev) {
   if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0) return FMD_EINVAL;
   if (n_mol == 0 || n_nodes == 0) return FMD_OK;
   if (!packed_dev || !pos || !atom_types || !mol_ptr || !energy || !forces || !workspace || !status)
@@ -900,10 +899,15 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
   const PackLayout PL = pack_layout(desc);
   const float* pk = reinterpret_cast<const float*>(packed_dev);
 
+  int kidx = 0;  // kernel index in launch order (fmd_schnet_kernel_name)
+  auto ev_begin = [&]() { if (ev) (void)hipEventRecord(ev[2 * kidx], s); };
+  auto ev_end = [&]() { if (ev) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
   const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
+  ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 256, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      (int)cap, ws.paircode, ws.pd, ws.npairs, status);
+  ev_end();
   FMD_CHECK_LAUNCH();
 
   const int ks0 = (desc->num_rbf + 1) / 2;
@@ -938,6 +942,7 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
     na.slab_stride = slab_stride; na.n_slabs = split; na.l1 = pk + o.l1; na.x1_out = ws.x1[l];
     na.n_nodes = n_nodes;
     na.l2 = na.b2 = na.l3 = na.b3 = nullptr; na.t_out = nullptr;
+    ev_begin();
     if (l == 0) {
       node_fwd_kernel<true><<<node_grid, 256, 0, s>>>(na);
     } else {
@@ -945,8 +950,11 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
       na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
       node_fwd_kernel<false><<<node_grid, 256, 0, s>>>(na);
     }
+    ev_end();
     FMD_CHECK_LAUNCH();
+    ev_begin();
     int rc = edge(true, l);
+    ev_end();
     if (rc != FMD_OK) return rc;
   }
   {
@@ -960,8 +968,10 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
       oa.po[k] = base; oa.bo[k] = base + SLICE; oa.pot[k] = base + SLICE + F;
     }
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
+    ev_begin();
     if (desc->num_out == 3) node_out_kernel<3><<<node_grid, 256, 0, s>>>(oa);
     else node_out_kernel<2><<<node_grid, 256, 0, s>>>(oa);
+    ev_end();
     FMD_CHECK_LAUNCH();
   }
   // ---------------- backward
@@ -971,18 +981,61 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
     ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = split;
     ba.t = ws.t[l]; ba.l3t = pk + o.l3t; ba.l2t = pk + o.l2t; ba.gagg = ws.gagg; ba.n_nodes = n_nodes;
     ba.l1t = nullptr;
+    ev_begin();
     if (l == L - 1) {
       node_bwd_kernel<false><<<node_grid, 256, 0, s>>>(ba);
     } else {
       ba.l1t = pk + block_off(PL, l + 1).l1t;
       node_bwd_kernel<true><<<node_grid, 256, 0, s>>>(ba);
     }
+    ev_end();
     FMD_CHECK_LAUNCH();
+    ev_begin();
     int rc = edge(false, l);
+    ev_end();
     if (rc != FMD_OK) return rc;
   }
+  ev_begin();
   finish_kernel<<<(unsigned)n_mol, 64, 3 * max_beads_per_mol * sizeof(float), s>>>(
       pos, mol_ptr, ws.paircode, ws.pd, ws.pgd, ws.npairs, (int)cap, ws.e_node, energy, forces);
+  ev_end();
   FMD_CHECK_LAUNCH();
   return FMD_OK;
+}
+
+extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev,
+                                        const float* pos, const int64_t* atom_types,
+                                        const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                                        int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                                        float* energy, float* forces, void* workspace,
+                                        int32_t* status, void* stream) {
+  return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
+                    max_pairs_per_mol, energy, forces, workspace, status, stream, nullptr);
+}
+
+extern "C" int fmd_schnet_kernel_count(const fmd_schnet_desc* desc) {
+  return desc_ok(desc) ? 4 * desc->num_blocks + 3 : FMD_EINVAL;
+}
+
+extern "C" const char* fmd_schnet_kernel_name(const fmd_schnet_desc* desc, int idx) {
+  if (!desc_ok(desc) || idx < 0 || idx >= 4 * desc->num_blocks + 3) return "";
+  const int L = desc->num_blocks;
+  if (idx == 0) return "pairs_kernel";
+  if (idx <= 2 * L) return (idx & 1) ? "node_fwd_kernel" : "edge_fwd_kernel";
+  if (idx == 2 * L + 1) return "node_out_kernel";
+  if (idx <= 4 * L + 1) return (idx & 1) ? "edge_bwd_kernel" : "node_bwd_kernel";
+  return "finish_kernel";
+}
+
+extern "C" int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* packed_dev,
+                                              const float* pos, const int64_t* atom_types,
+                                              const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                                              int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                                              float* energy, float* forces, void* workspace,
+                                              int32_t* status, void* stream, void** events,
+                                              int64_t n_events) {
+  if (!desc_ok(desc) || !events || n_events < 2 * (4 * desc->num_blocks + 3)) return FMD_EINVAL;
+  return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
+                    max_pairs_per_mol, energy, forces, workspace, status, stream,
+                    reinterpret_cast<hipEvent_t*>(events));
 }

@@ -110,8 +110,15 @@ class FusedSchNetEngine:
         off = (-self._ws.data_ptr()) % 256
         return ctypes.c_void_p(self._ws.data_ptr() + off)
 
-    def energy_forces(self, pos, atom_types, mol_ptr, max_beads_per_mol: int = 0):
-        """energy[B] f32, forces[N,3] f32 of the batch; everything enqueued on the current stream."""
+    def kernel_names(self):
+        lib = _ffi.lib()
+        n = lib.fmd_schnet_kernel_count(ctypes.byref(self.desc))
+        return [lib.fmd_schnet_kernel_name(ctypes.byref(self.desc), k).decode() for k in range(n)]
+
+    def energy_forces(self, pos, atom_types, mol_ptr, max_beads_per_mol: int = 0, events=None):
+        """energy[B] f32, forces[N,3] f32 of the batch; everything enqueued on the current stream.
+        ``events``: optional ctypes array of 2*len(kernel_names()) hipEvent_t handles recorded
+        before/after each kernel (measurement only)."""
         _ffi.require_gpu(pos, atom_types, mol_ptr)
         pos = pos.detach()
         assert pos.dtype == torch.float32 and pos.is_contiguous() and atom_types.dtype == torch.int64
@@ -123,9 +130,13 @@ class FusedSchNetEngine:
         cap = max(32, (max_beads_per_mol * (max_beads_per_mol - 1) // 2 + 31) // 32 * 32)
         energy = torch.empty(n_mol, dtype=torch.float32, device=pos.device)
         forces = torch.empty(n_nodes, 3, dtype=torch.float32, device=pos.device)
-        call("fmd_schnet_energy_forces", ctypes.byref(self.desc), ptr(self.packed), ptr(pos),
-             ptr(atom_types), ptr(mol_ptr), n_mol, n_nodes, max_beads_per_mol, cap, ptr(energy),
-             ptr(forces), self._workspace(n_mol, n_nodes, cap), ptr(self.status), stream())
+        args = (ctypes.byref(self.desc), ptr(self.packed), ptr(pos), ptr(atom_types), ptr(mol_ptr), n_mol,
+                n_nodes, max_beads_per_mol, cap, ptr(energy), ptr(forces),
+                self._workspace(n_mol, n_nodes, cap), ptr(self.status), stream())
+        if events is None:
+            call("fmd_schnet_energy_forces", *args)
+        else:
+            call("fmd_schnet_energy_forces_timed", *args, events, len(events))
         return energy, forces
 
 

@@ -206,6 +206,19 @@ int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev
                              float* energy, float* forces, void* workspace, int32_t* status,
                              void* stream);
 
+/* Measurement hooks (bench.py): the engine launches fmd_schnet_kernel_count(desc) kernels per call,
+ * in a fixed order named by fmd_schnet_kernel_name.  The _timed variant is the same call that also
+ * records events[2k] / events[2k+1] (hipEvent_t created by the caller with timing enabled) on `stream`
+ * immediately before / after kernel k, so per-kernel durations come from the stream the kernels run on. */
+int fmd_schnet_kernel_count(const fmd_schnet_desc* desc);
+const char* fmd_schnet_kernel_name(const fmd_schnet_desc* desc, int idx);
+int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
+                                   const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
+                                   int64_t n_nodes, int64_t max_beads_per_mol,
+                                   int64_t max_pairs_per_mol, float* energy, float* forces,
+                                   void* workspace, int32_t* status, void* stream, void** events,
+                                   int64_t n_events);
+
 /* ---------------------------------------------------------------------------------------------
  * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).
  *   pre : v += .5 dt f/m ; x += .5 dt v ; v = vscale v + noisescale sqrt(1/(beta m)) * noise ; x += .5 dt v
