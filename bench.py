@@ -76,7 +76,8 @@ def cpu_baseline(model, args, seconds):
         if isinstance(m, torch.nn.Linear):
             p["out"].append({"w": m.weight.detach().cpu(),
                              "b": None if m.bias is None else m.bias.detach().cpu()})
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share of the host (os.cpu_count() reports the whole machine)
+    threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     n_mol = 8
     pos, types, ptr, masses = synthetic.batch(n_mol, args.beads, 5.0)

@@ -154,11 +154,15 @@ __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// pair list (undirected i<j, strict d2 < rc2 with unfused fp32, sorted by i then j)
+// pair list: undirected i<j, strict d2 < rc2 with unfused fp32, sorted by centre i then j.
+// Each centre's entries are padded to a multiple of 8 (pad = (i,i) with d = rc, whose cutoff is 0),
+// so an 8-entry SEGMENT of a 32-entry tile always belongs to one centre: inside a segment the
+// neighbours j are distinct and the centre is shared, which lets the edge kernels accumulate with
+// plain LDS read-modify-write (no float atomics) and one in-register reduction per segment.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ pos,
                                                     const int64_t* __restrict__ mol_ptr, float rc2,
-                                                    int cap, uint32_t* __restrict__ paircode,
+                                                    float rc, int cap, uint32_t* __restrict__ paircode,
                                                     float* __restrict__ pd, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
-  int* rowstart = reinterpret_cast<int*>(sz + n);  // [n + 1]
-  __shared__ int wave_tot[4];
+  int* rowcount = reinterpret_cast<int*>(sz + n);  // [n]
+  __shared__ int wave_tot[4], wave_real[4];
   for (int i = tid; i < n; i += 256) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
   // rows are dealt in contiguous chunks so one block scan orders them
   const int per = (n + 255) / 256;
   const int i_lo = min(n, tid * per), i_hi = min(n, i_lo + per);
-  int mine = 0;
+  int mine = 0, mine_real = 0;
   for (int i = i_lo; i < i_hi; ++i) {
     const float xi = sx[i], yi = sy[i], zi = sz[i];
     int c = 0;
@@ -188,10 +192,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
       const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       c += d2 < rc2 ? 1 : 0;
     }
-    rowstart[i] = c;
-    mine += c;
+    rowcount[i] = c;
+    mine += (c + 7) & ~7;
+    mine_real += c;
   }
-  // exclusive scan of per-thread totals
+  // exclusive scan of per-thread padded totals
   const int lane = tid & 63, wv = tid >> 6;
   int incl = mine;
 #pragma unroll
@@ -199,32 +204,45 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
     const int t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
+  int real_w = mine_real;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) real_w += __shfl_xor(real_w, o, 64);
   if (lane == 63) wave_tot[wv] = incl;
+  if (lane == 0) wave_real[wv] = real_w;
   __syncthreads();
   int base = incl - mine;
   for (int q = 0; q < wv; ++q) base += wave_tot[q];
   const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  uint32_t* code_out = paircode + (int64_t)m * cap;
+  float* d_out = pd + (int64_t)m * cap;
   for (int i = i_lo; i < i_hi; ++i) {
     const float xi = sx[i], yi = sy[i], zi = sz[i];
     int k = base;
-    base += rowstart[i];
+    const int kend = base + ((rowcount[i] + 7) & ~7);
+    base = kend;
     for (int j = i + 1; j < n; ++j) {
       const float dx = __fsub_rn(sx[j], xi), dy = __fsub_rn(sy[j], yi), dz = __fsub_rn(sz[j], zi);
       const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       if (d2 < rc2) {
         if (k < cap) {
-          paircode[(int64_t)m * cap + k] = (uint32_t)i | ((uint32_t)j << 16);
-          pd[(int64_t)m * cap + k] = sqrtf(d2);
+          code_out[k] = (uint32_t)i | ((uint32_t)j << 16);
+          d_out[k] = sqrtf(d2);
         }
         ++k;
       }
     }
+    for (; k < kend; ++k)
+      if (k < cap) {
+        code_out[k] = (uint32_t)i | ((uint32_t)i << 16);
+        d_out[k] = rc;
+      }
   }
   if (tid == 0) {
-    npairs[m] = min(total, cap);
+    const int real = wave_real[0] + wave_real[1] + wave_real[2] + wave_real[3];
+    npairs[m] = min(total, cap) & ~7;
     if (total > cap) status[0] = FMD_ECAPACITY;
     atomicMax(&status[1], total);
-    atomicAdd(&status[2], total);
+    atomicAdd(&status[2], real);
   }
 }
 
@@ -261,29 +279,54 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   const int n = (int)(a.mol_ptr[m + 1] - a0);
   const int np = a.npairs[m];
   for (int i = tid * 4; i < n * F; i += 1024) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  float w0[KS0], w1[64], b0r[16];
+  float w0[KS0], w1[64], b0r[16], cen[KS0];
 #pragma unroll
   for (int s = 0; s < KS0; ++s) w0[s] = a.p0[(w * 32 + s) * 64 + lane];
 #pragma unroll
   for (int s = 0; s < 64; ++s) w1[s] = a.p1[(w * 64 + s) * 64 + lane];
 #pragma unroll
   for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+#pragma unroll
+  for (int s = 0; s < KS0; ++s) cen[s] = a.centers[2 * s + h];
   const int col = 32 * w + c32;
   const float* x1m = a.x1 + a0 * F + col;
+  const uint32_t* pcode = a.paircode + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
   __syncthreads();
   const int ntiles = (np + 31) >> 5;
+  // software pipeline: pair codes / distances of the next tile are fetched during the current one
+  // (loads are unconditional on a clamped index so no wait is forced at the issue point; the
+  //  validity select happens when the values are consumed, one tile later)
+  uint32_t code_n = pcode[min(split * 32 + c32, a.cap - 1)];
+  float d_n = pdist[min(split * 32 + c32, a.cap - 1)];
   for (int t = split; t < ntiles; t += a.n_split) {
-    const int p = t * 32 + c32;
-    const bool valid = p < np;
-    const uint32_t code = valid ? a.paircode[(int64_t)m * a.cap + p] : 0u;
-    const float d = valid ? a.pd[(int64_t)m * a.cap + p] : a.rc;
+    const bool valid = t * 32 + c32 < np;
+    const uint32_t code = valid ? code_n : 0u;
+    const float d = valid ? d_n : a.rc;
+    {
+      const int pn = min((t + a.n_split) * 32 + c32, a.cap - 1);
+      code_n = pcode[pn];
+      d_n = pdist[pn];
+    }
     const float C = fmd_cutoff(d, a.rc);
+    // rows of this lane's 16 accumulator registers: issue the x1 gathers now, they land under the MFMAs
+    int ipr[16], jpr[16];
+    float Cr[16], xi[16], xj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_row(r, h);
+      const uint32_t cp = __shfl(code, row, 64);
+      Cr[r] = __shfl(C, row, 64);
+      ipr[r] = cp & 0xffff;
+      jpr[r] = cp >> 16;
+      xi[r] = x1m[ipr[r] * F];
+      xj[r] = x1m[jpr[r] * F];
+    }
     // ---- L0: hidden^T slice = W0 slice . rbf^T  (lane = pair, registers = features)
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
-      const float ck = h ? a.centers[2 * s + 1] : a.centers[2 * s];
-      const float diff = d - ck;
+      const float diff = d - cen[s];
       const float b = __expf(a.gamma * diff * diff) * C;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], b, acc, 0, 0, 0);
     }
@@ -308,16 +351,23 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
       }
     }
     // ---- messages: agg[j] += x1[i] * W, agg[i] += x1[j] * W  (this wave's 32 features)
+    // Segment g (registers 4g..4g+3 of both lane halves) belongs to one centre with distinct
+    // neighbours: neighbour rows are updated by plain read-modify-write, the centre row once.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tile_row(r, h);
-      const uint32_t cp = __shfl(code, row, 64);
-      const float Cp = __shfl(C, row, 64);
-      const int ip = cp & 0xffff, jp = cp >> 16;
-      const float W = fl[r] * Cp;
-      const float xi = x1m[ip * F], xj = x1m[jp * F];
-      atomicAdd(&agg[jp * F + col], xi * W);
-      atomicAdd(&agg[ip * F + col], xj * W);
+    for (int g = 0; g < 4; ++g) {
+      float Wq[4], vj[4];
+      float si = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Wq[q] = fl[4 * g + q] * Cr[4 * g + q];
+        vj[q] = agg[jpr[4 * g + q] * F + col];
+        si += xj[4 * g + q] * Wq[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) agg[jpr[4 * g + q] * F + col] = vj[q] + xi[4 * g + q] * Wq[q];
+      si += __shfl_xor(si, 32, 64);
+      const int ic = ipr[4 * g];
+      agg[ic * F + col] += si;  // both halves store the same value to the same address
     }
     __syncthreads();
   }
@@ -340,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
   const int np = a.npairs[m];
   if (NEED_GX1)
     for (int i = tid * 4; i < n * F; i += 1024) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  float w0[KS0], w1[64], w1t[64], b0r[16];
+  float w0[KS0], w1[64], w1t[64], b0r[16], cen[KS0];
 #pragma unroll
   for (int s = 0; s < KS0; ++s) w0[s] = a.p0[(w * 32 + s) * 64 + lane];
 #pragma unroll
@@ -349,24 +399,52 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
   for (int s = 0; s < 64; ++s) w1t[s] = a.p1t[(w * 64 + s) * 64 + lane];
 #pragma unroll
   for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+#pragma unroll
+  for (int s = 0; s < KS0; ++s) cen[s] = a.centers[2 * s + h];
   const int col = 32 * w + c32;
   const float* x1m = a.x1 + a0 * F + col;
   const float* gam = a.gagg + a0 * F + col;
+  const uint32_t* pcode = a.paircode + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  float* pgd = a.pgd + (int64_t)m * a.cap;
   __syncthreads();
   const int ntiles = (np + 31) >> 5;
+  // (loads are unconditional on a clamped index so no wait is forced at the issue point; the
+  //  validity select happens when the values are consumed, one tile later)
+  uint32_t code_n = pcode[min(split * 32 + c32, a.cap - 1)];
+  float d_n = pdist[min(split * 32 + c32, a.cap - 1)];
   for (int t = split; t < ntiles; t += a.n_split) {
     const int p = t * 32 + c32;
     const bool valid = p < np;
-    const uint32_t code = valid ? a.paircode[(int64_t)m * a.cap + p] : 0u;
-    const float d = valid ? a.pd[(int64_t)m * a.cap + p] : a.rc;
+    const uint32_t code = valid ? code_n : 0u;
+    const float d = valid ? d_n : a.rc;
+    {
+      const int pn = min((t + a.n_split) * 32 + c32, a.cap - 1);
+      code_n = pcode[pn];
+      d_n = pdist[pn];
+    }
     float C, dC;
     fmd_cutoff2(d, a.rc, C, dC);
+    // gathers of x1 and d/d(agg) rows for the 16 accumulator registers: in flight under the MFMAs
+    int ipr[16], jpr[16];
+    float Cr[16], xi[16], xj[16], gi[16], gj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tile_row(r, h);
+      const uint32_t cp = __shfl(code, row, 64);
+      Cr[r] = __shfl(C, row, 64);
+      ipr[r] = cp & 0xffff;
+      jpr[r] = cp >> 16;
+      xi[r] = x1m[ipr[r] * F];
+      xj[r] = x1m[jpr[r] * F];
+      gi[r] = gam[ipr[r] * F];
+      gj[r] = gam[jpr[r] * F];
+    }
     // ---- L0 and its forward-mode derivative: z = W0 rbf(d), z' = W0 d(rbf)/dd
     f32x16 az = zero16(), azp = zero16();
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
-      const float ck = h ? a.centers[2 * s + 1] : a.centers[2 * s];
-      const float diff = d - ck;
+      const float diff = d - cen[s];
       const float raw = __expf(a.gamma * diff * diff);
       const float b = raw * C;
       const float bp = raw * (2.0f * a.gamma * diff * C + dC);
@@ -400,19 +478,24 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
     __syncthreads();  // every wave is done with the hidden tile; buf becomes the gW tile
     // ---- gW = x1[i] gagg[j] + x1[j] gagg[i]; gx1[i] += gagg[j] W, gx1[j] += gagg[i] W
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tile_row(r, h);
-      const uint32_t cp = __shfl(code, row, 64);
-      const float Cp = __shfl(C, row, 64);
-      const int ip = cp & 0xffff, jp = cp >> 16;
-      const float xi = x1m[ip * F], xj = x1m[jp * F];
-      const float gi = gam[ip * F], gj = gam[jp * F];
-      if (NEED_GX1) {
-        const float W = fl[r] * Cp;
-        atomicAdd(&gx1[ip * F + col], gj * W);
-        atomicAdd(&gx1[jp * F + col], gi * W);
+    for (int r = 0; r < 16; ++r) buf[tile_row(r, h) * LDA + col] = xi[r] * gj[r] + xj[r] * gi[r];
+    if (NEED_GX1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float Wq[4], vj[4];
+        float si = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Wq[q] = fl[4 * g + q] * Cr[4 * g + q];
+          vj[q] = gx1[jpr[4 * g + q] * F + col];
+          si += gj[4 * g + q] * Wq[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gx1[jpr[4 * g + q] * F + col] = vj[q] + gi[4 * g + q] * Wq[q];
+        si += __shfl_xor(si, 32, 64);
+        const int ic = ipr[4 * g];
+        gx1[ic * F + col] += si;
       }
-      buf[row * LDA + col] = xi * gj + xj * gi;
     }
     __syncthreads();
     // ---- u^T slice = W1^T slice . gW^T   (lane = pair, registers = hidden features)
@@ -441,8 +524,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
     __syncthreads();
     if (w == 0 && h == 0 && valid) {
       const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
-      float* g = a.pgd + (int64_t)m * a.cap + p;
-      *g = FIRST ? sum : *g + sum;
+      pgd[p] = FIRST ? sum : pgd[p] + sum;
     }
   }
   if (NEED_GX1) {
@@ -906,7 +988,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 256, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
-                                                     (int)cap, ws.paircode, ws.pd, ws.npairs, status);
+                                                     desc->cutoff, (int)cap, ws.paircode, ws.pd,
+                                                     ws.npairs, status);
   ev_end();
   FMD_CHECK_LAUNCH();
 

@@ -127,7 +127,9 @@ class FusedSchNetEngine:
             max_beads_per_mol = int((mol_ptr[1:] - mol_ptr[:-1]).max().item()) if n_mol else 1
         if max_beads_per_mol > MAX_BEADS:
             raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {MAX_BEADS}")
-        cap = max(32, (max_beads_per_mol * (max_beads_per_mol - 1) // 2 + 31) // 32 * 32)
+        # every pair plus <= 7 pad entries per centre (8-entry segments): can never overflow
+        a_ = max_beads_per_mol
+        cap = max(32, (a_ * (a_ - 1) // 2 + 8 * a_ + 31) // 32 * 32)
         energy = torch.empty(n_mol, dtype=torch.float32, device=pos.device)
         forces = torch.empty(n_nodes, 3, dtype=torch.float32, device=pos.device)
         args = (ctypes.byref(self.desc), ptr(self.packed), ptr(pos), ptr(atom_types), ptr(mol_ptr), n_mol,

@@ -198,7 +198,8 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
  * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
 /* max_beads_per_mol: upper bound on beads of one molecule (<= 286: the per-molecule aggregate lives
  * in LDS; larger molecules return FMD_EUNSUPPORTED and take the operator path).
- * max_pairs_per_mol: capacity of the per-molecule pair list; A(A-1)/2 can never overflow.
+ * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
+ *   multiples of 8 entries; A(A-1)/2 + 8A can never overflow.
  * workspace: fmd_schnet_workspace_bytes bytes, 256-byte aligned. */
 int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
                              const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
