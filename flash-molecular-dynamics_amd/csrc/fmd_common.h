@@ -56,6 +56,13 @@ __device__ __forceinline__ float fmd_tanh(float x) {
   return r;
 }
 
+// branch-free tanh for the fused kernels: 1 - 2 rcp(e^{2x} + 1); |abs err| ~ 2e-7, exact at +-inf.
+// (absolute accuracy is what the consumers need: the value feeds a contraction and 1 - t^2)
+__device__ __forceinline__ float fmd_tanh_fast(float x) {
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 // the reference's Triton tanh for the W16A16 kernels (kernels/cfconv_kernels.py:449-454)
 __device__ __forceinline__ float fmd_tanh_clamped(float x) {
   float xc = fminf(fmaxf(x, -10.0f), 10.0f);

@@ -162,8 +162,10 @@ __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ pos,
                                                     const int64_t* __restrict__ mol_ptr, float rc2,
-                                                    float rc, int cap, uint32_t* __restrict__ paircode,
-                                                    float* __restrict__ pd, int32_t* __restrict__ npairs,
+                                                    float rc, int cap, uint32_t* __restrict__ poi,
+                                                    uint32_t* __restrict__ poj,
+                                                    float* __restrict__ pd, float* __restrict__ pc,
+                                                    float* __restrict__ pdc, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.x, tid = threadIdx.x;
@@ -213,8 +215,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
   int base = incl - mine;
   for (int q = 0; q < wv; ++q) base += wave_tot[q];
   const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-  uint32_t* code_out = paircode + (int64_t)m * cap;
+  uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
+  uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
   float* d_out = pd + (int64_t)m * cap;
+  float* c_out = pc + (int64_t)m * cap;
+  float* dc_out = pdc + (int64_t)m * cap;
   for (int i = i_lo; i < i_hi; ++i) {
     const float xi = sx[i], yi = sy[i], zi = sz[i];
     int k = base;
@@ -225,17 +230,39 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
       const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       if (d2 < rc2) {
         if (k < cap) {
-          code_out[k] = (uint32_t)i | ((uint32_t)j << 16);
-          d_out[k] = sqrtf(d2);
+          oi_out[k] = (uint32_t)i * (F * 4);
+          oj_out[k] = (uint32_t)j * (F * 4);
+          const float d = sqrtf(d2);
+          float C, dC;
+          fmd_cutoff2(d, rc, C, dC);  // cosine cutoff and derivative, once per pair per timestep
+          d_out[k] = d;
+          c_out[k] = C;
+          dc_out[k] = dC;
         }
         ++k;
       }
     }
     for (; k < kend; ++k)
       if (k < cap) {
-        code_out[k] = (uint32_t)i | ((uint32_t)i << 16);
+        oi_out[k] = (uint32_t)i * (F * 4);
+        oj_out[k] = (uint32_t)i * (F * 4);
         d_out[k] = rc;
+        c_out[k] = 0.f;
+        dc_out[k] = 0.f;
       }
+  }
+  // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
+  // need a validity test
+  {
+    const int tot_c = min(total, cap) & ~7;
+    const int tot32 = min((tot_c + 31) & ~31, cap);
+    for (int k = tot_c + tid; k < tot32; k += 256) {
+      oi_out[k] = 0u;
+      oj_out[k] = 0u;
+      d_out[k] = rc;
+      c_out[k] = 0.f;
+      dc_out[k] = 0.f;
+    }
   }
   if (tid == 0) {
     const int real = wave_real[0] + wave_real[1] + wave_real[2] + wave_real[3];
@@ -250,8 +277,11 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
 // edge kernels
 // ---------------------------------------------------------------------------------------------
 struct EdgeArgs {
-  const uint32_t* paircode;
+  const uint32_t* poi;     // centre row byte offsets (i * 512)
+  const uint32_t* poj;     // neighbour row byte offsets (j * 512)
   const float* pd;
+  const float* pc;         // C(d) per pair
+  const float* pdc;        // C'(d) per pair
   float* pgd;              // dE/dd per pair (backward)
   const int32_t* npairs;
   const int64_t* mol_ptr;
@@ -266,9 +296,12 @@ struct EdgeArgs {
   int64_t slab_stride;
   float gamma, rc;
   int cap, n_split;
+  unsigned long long* stamps;  // diagnostic builds only
 };
 
-template <int KS0>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS0, bool STAMP>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hid = smem;                 // [32][LDA]
@@ -288,41 +321,69 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
 #pragma unroll
   for (int s = 0; s < KS0; ++s) cen[s] = a.centers[2 * s + h];
-  const int col = 32 * w + c32;
-  const float* x1m = a.x1 + a0 * F + col;
-  const uint32_t* pcode = a.paircode + (int64_t)m * a.cap;
+  const uint32_t col4 = (uint32_t)(32 * w + c32) * 4u;         // byte offset of this lane's feature
+  const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+  char* aggb = reinterpret_cast<char*>(agg);
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
-  __syncthreads();
+  const float* pcut = a.pc + (int64_t)m * a.cap;
   const int ntiles = (np + 31) >> 5;
-  // software pipeline: pair codes / distances of the next tile are fetched during the current one
-  // (loads are unconditional on a clamped index so no wait is forced at the issue point; the
-  //  validity select happens when the values are consumed, one tile later)
-  uint32_t code_n = pcode[min(split * 32 + c32, a.cap - 1)];
-  float d_n = pdist[min(split * 32 + c32, a.cap - 1)];
-  for (int t = split; t < ntiles; t += a.n_split) {
-    const bool valid = t * 32 + c32 < np;
-    const uint32_t code = valid ? code_n : 0u;
-    const float d = valid ? d_n : a.rc;
-    {
-      const int pn = min((t + a.n_split) * 32 + c32, a.cap - 1);
-      code_n = pcode[pn];
-      d_n = pdist[pn];
+  const int S = a.n_split;
+
+  // Tile meta, fetched one tile ahead with unconditional loads (index clamped into the list):
+  //   lane = pair view    : d, C of entry 32 t + c32                        (feeds the rbf / L0)
+  //   lane = feature view : row offsets and C of the 16 entries this lane's accumulator registers
+  //                         stand for, entries 8q + 4h + {0..3}, q = 0..3    (16-byte broadcast loads)
+  float d_n, c_n;
+  u32x4 oi_n[4], oj_n[4];
+  f32x4 cr_n[4];
+  auto fetch = [&](int t) {
+    const int base = min(t * 32, a.cap - 32);
+    d_n = pdist[base + c32];
+    c_n = pcut[base + c32];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      oi_n[q] = *reinterpret_cast<const u32x4*>(poi + base + 8 * q + 4 * h);
+      oj_n[q] = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+      cr_n[q] = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
     }
-    const float C = fmd_cutoff(d, a.rc);
-    // rows of this lane's 16 accumulator registers: issue the x1 gathers now, they land under the MFMAs
-    int ipr[16], jpr[16];
-    float Cr[16], xi[16], xj[16];
+  };
+  // state of the tile in flight: register r = 4q + e  <->  entry 8q + 4h + e
+  uint32_t oi_c[16], oj_c[16];
+  float cr_c[16], xi_c[16], xj_c[16];
+
+  // diagnostic build only (STAMP): per-phase cycle totals of this wave -> a.stamps[wg][wave][phase]
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+  auto stamp = [&](int ph) {
+    if (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+      tacc[ph] += now - tprev;
+      tprev = now;
+    }
+  };
+  auto stage = [&](int t) {
+    const float d = d_n, C = c_n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oi_c[4 * q + e] = oi_n[q][e] + col4;
+        oj_c[4 * q + e] = oj_n[q][e] + col4;
+        cr_c[4 * q + e] = cr_n[q][e];
+      }
+    fetch(t + S);
+    // x1 gathers: issued now, first used in the message phase (after L1)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = tile_row(r, h);
-      const uint32_t cp = __shfl(code, row, 64);
-      Cr[r] = __shfl(C, row, 64);
-      ipr[r] = cp & 0xffff;
-      jpr[r] = cp >> 16;
-      xi[r] = x1m[ipr[r] * F];
-      xj[r] = x1m[jpr[r] * F];
+      xi_c[r] = *reinterpret_cast<const float*>(x1b + oi_c[r]);
+      xj_c[r] = *reinterpret_cast<const float*>(x1b + oj_c[r]);
     }
-    // ---- L0: hidden^T slice = W0 slice . rbf^T  (lane = pair, registers = features)
+    stamp(5);  // meta select, prefetch + gather issue
+    // L0: hidden^T slice = W0 slice . rbf^T  (lane = pair, registers = features)
     f32x16 acc = zero16();
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
@@ -330,15 +391,46 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
       const float b = __expf(a.gamma * diff * diff) * C;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], b, acc, 0, 0, 0);
     }
+    if (STAMP) asm volatile("" : "+v"(acc));
+    stamp(6);  // L0 (+rbf)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmd_tanh(acc[4 * q + e] + b0r[4 * q + e]);
+      for (int e = 0; e < 4; ++e) v[e] = fmd_tanh_fast(acc[4 * q + e] + b0r[4 * q + e]);
       *reinterpret_cast<f32x4*>(hid + c32 * LDA + 32 * w + 8 * q + 4 * h) = v;
     }
+  };
+  // Segment q (registers 4q..4q+3 of both lane halves) belongs to one centre with distinct
+  // neighbours: neighbour rows are updated by plain read-modify-write, the centre row once.
+  auto message = [&](const f32x16& fl) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float vj[4], Wq[4];
+      float si = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Wq[e] = fl[4 * q + e] * cr_c[4 * q + e];
+        vj[e] = *reinterpret_cast<float*>(aggb + oj_c[4 * q + e]);
+        si += xj_c[4 * q + e] * Wq[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        *reinterpret_cast<float*>(aggb + oj_c[4 * q + e]) = vj[e] + xi_c[4 * q + e] * Wq[e];
+      si += __shfl_xor(si, 32, 64);
+      float* ci = reinterpret_cast<float*>(aggb + oi_c[4 * q]);
+      *ci += si;  // both halves store the same value to the same address
+    }
+  };
+
+  fetch(split);
+  __syncthreads();
+  if (STAMP) tprev = __builtin_readcyclecounter();
+  for (int t = split; t < ntiles; t += S) {
+    stage(t);
+    stamp(0);  // tanh, hidden write
     __syncthreads();
-    // ---- L1: filt slice = hidden . W1^T slice   (lane = feature, registers = pairs)
+    stamp(1);  // barrier A
     f32x16 fl = zero16();
     {
       const float* ap = hid + c32 * LDA + 64 * h;
@@ -350,26 +442,16 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
           fl = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], w1[4 * s4 + q], fl, 0, 0, 0);
       }
     }
-    // ---- messages: agg[j] += x1[i] * W, agg[i] += x1[j] * W  (this wave's 32 features)
-    // Segment g (registers 4g..4g+3 of both lane halves) belongs to one centre with distinct
-    // neighbours: neighbour rows are updated by plain read-modify-write, the centre row once.
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float Wq[4], vj[4];
-      float si = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Wq[q] = fl[4 * g + q] * Cr[4 * g + q];
-        vj[q] = agg[jpr[4 * g + q] * F + col];
-        si += xj[4 * g + q] * Wq[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) agg[jpr[4 * g + q] * F + col] = vj[q] + xi[4 * g + q] * Wq[q];
-      si += __shfl_xor(si, 32, 64);
-      const int ic = ipr[4 * g];
-      agg[ic * F + col] += si;  // both halves store the same value to the same address
-    }
+    if (STAMP) asm volatile("" : "+v"(fl));
+    stamp(2);  // L1
+    message(fl);
+    stamp(3);  // message
     __syncthreads();
+    stamp(4);  // barrier B
+  }
+  if (STAMP && lane == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
+    for (int k = 0; k < 8; ++k) o[k] = tacc[k];
   }
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
@@ -402,43 +484,58 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
 #pragma unroll
   for (int s = 0; s < KS0; ++s) cen[s] = a.centers[2 * s + h];
   const int col = 32 * w + c32;
-  const float* x1m = a.x1 + a0 * F + col;
-  const float* gam = a.gagg + a0 * F + col;
-  const uint32_t* pcode = a.paircode + (int64_t)m * a.cap;
+  const uint32_t col4 = (uint32_t)col * 4u;
+  const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+  const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F);
+  char* gx1b = reinterpret_cast<char*>(gx1);
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const float* pdcut = a.pdc + (int64_t)m * a.cap;
   float* pgd = a.pgd + (int64_t)m * a.cap;
-  __syncthreads();
   const int ntiles = (np + 31) >> 5;
-  // (loads are unconditional on a clamped index so no wait is forced at the issue point; the
-  //  validity select happens when the values are consumed, one tile later)
-  uint32_t code_n = pcode[min(split * 32 + c32, a.cap - 1)];
-  float d_n = pdist[min(split * 32 + c32, a.cap - 1)];
-  for (int t = split; t < ntiles; t += a.n_split) {
-    const int p = t * 32 + c32;
-    const bool valid = p < np;
-    const uint32_t code = valid ? code_n : 0u;
-    const float d = valid ? d_n : a.rc;
-    {
-      const int pn = min((t + a.n_split) * 32 + c32, a.cap - 1);
-      code_n = pcode[pn];
-      d_n = pdist[pn];
+  const int S = a.n_split;
+
+  // tile meta one tile ahead (see edge_fwd_kernel); wave 0 also prefetches the running dE/dd
+  float d_n, c_n, dc_n, gd_n = 0.f;
+  u32x4 oi_n[4], oj_n[4];
+  f32x4 cr_n[4];
+  auto fetch = [&](int t) {
+    const int base = min(t * 32, a.cap - 32);
+    d_n = pdist[base + c32];
+    c_n = pcut[base + c32];
+    dc_n = pdcut[base + c32];
+    if (!FIRST) gd_n = pgd[base + c32];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      oi_n[q] = *reinterpret_cast<const u32x4*>(poi + base + 8 * q + 4 * h);
+      oj_n[q] = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+      cr_n[q] = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
     }
-    float C, dC;
-    fmd_cutoff2(d, a.rc, C, dC);
-    // gathers of x1 and d/d(agg) rows for the 16 accumulator registers: in flight under the MFMAs
-    int ipr[16], jpr[16];
-    float Cr[16], xi[16], xj[16], gi[16], gj[16];
+  };
+  fetch(split);
+  __syncthreads();
+  for (int t = split; t < ntiles; t += S) {
+    const float d = d_n, C = c_n, dC = dc_n, gd_old = gd_n;
+    uint32_t oi_c[16], oj_c[16];
+    float cr_c[16], xi[16], xj[16], gi[16], gj[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oi_c[4 * q + e] = oi_n[q][e] + col4;
+        oj_c[4 * q + e] = oj_n[q][e] + col4;
+        cr_c[4 * q + e] = cr_n[q][e];
+      }
+    fetch(t + S);
+    // gathers of x1 and d/d(agg) rows: in flight under the L0 / L1 MFMAs
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = tile_row(r, h);
-      const uint32_t cp = __shfl(code, row, 64);
-      Cr[r] = __shfl(C, row, 64);
-      ipr[r] = cp & 0xffff;
-      jpr[r] = cp >> 16;
-      xi[r] = x1m[ipr[r] * F];
-      xj[r] = x1m[jpr[r] * F];
-      gi[r] = gam[ipr[r] * F];
-      gj[r] = gam[jpr[r] * F];
+      xi[r] = *reinterpret_cast<const float*>(x1b + oi_c[r]);
+      xj[r] = *reinterpret_cast<const float*>(x1b + oj_c[r]);
+      gi[r] = *reinterpret_cast<const float*>(gab + oi_c[r]);
+      gj[r] = *reinterpret_cast<const float*>(gab + oj_c[r]);
     }
     // ---- L0 and its forward-mode derivative: z = W0 rbf(d), z' = W0 d(rbf)/dd
     f32x16 az = zero16(), azp = zero16();
@@ -457,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        hr[4 * q + e] = fmd_tanh(az[4 * q + e] + b0r[4 * q + e]);
+        hr[4 * q + e] = fmd_tanh_fast(az[4 * q + e] + b0r[4 * q + e]);
         v[e] = hr[4 * q + e];
       }
       *reinterpret_cast<f32x4*>(buf + c32 * LDA + 32 * w + 8 * q + 4 * h) = v;
@@ -476,29 +573,12 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
       }
     }
     __syncthreads();  // every wave is done with the hidden tile; buf becomes the gW tile
-    // ---- gW = x1[i] gagg[j] + x1[j] gagg[i]; gx1[i] += gagg[j] W, gx1[j] += gagg[i] W
+    // ---- gW = x1[i] gagg[j] + x1[j] gagg[i]
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[tile_row(r, h) * LDA + col] = xi[r] * gj[r] + xj[r] * gi[r];
-    if (NEED_GX1) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float Wq[4], vj[4];
-        float si = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          Wq[q] = fl[4 * g + q] * Cr[4 * g + q];
-          vj[q] = gx1[jpr[4 * g + q] * F + col];
-          si += gj[4 * g + q] * Wq[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gx1[jpr[4 * g + q] * F + col] = vj[q] + gi[4 * g + q] * Wq[q];
-        si += __shfl_xor(si, 32, 64);
-        const int ic = ipr[4 * g];
-        gx1[ic * F + col] += si;
-      }
-    }
     __syncthreads();
-    // ---- u^T slice = W1^T slice . gW^T   (lane = pair, registers = hidden features)
+    // ---- u^T slice = W1^T slice . gW^T   (lane = pair, registers = hidden features), with the
+    //      aggregate update gx1[i] += gagg[j] W, gx1[j] += gagg[i] W in the same scheduling region
     f32x16 u = zero16();
     {
       const float* bp = buf + c32 * LDA + 64 * h;
@@ -508,6 +588,25 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           u = __builtin_amdgcn_mfma_f32_32x32x2f32(w1t[4 * s4 + q], b4[q], u, 0, 0, 0);
+      }
+    }
+    if (NEED_GX1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float Wq[4], vj[4];
+        float si = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Wq[e] = fl[4 * q + e] * cr_c[4 * q + e];
+          vj[e] = *reinterpret_cast<float*>(gx1b + oj_c[4 * q + e]);
+          si += gj[4 * q + e] * Wq[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<float*>(gx1b + oj_c[4 * q + e]) = vj[e] + gi[4 * q + e] * Wq[e];
+        si += __shfl_xor(si, 32, 64);
+        float* ci = reinterpret_cast<float*>(gx1b + oi_c[4 * q]);
+        *ci += si;
       }
     }
     // dE/dd = sum_h [C u (1-h^2)] z'  +  C' sum_h u h
@@ -522,9 +621,9 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
     tot += __shfl_xor(tot, 32, 64);
     if (h == 0) red[w * 32 + c32] = tot;
     __syncthreads();
-    if (w == 0 && h == 0 && valid) {
+    if (w == 0 && h == 0) {
       const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
-      pgd[p] = FIRST ? sum : pgd[p] + sum;
+      pgd[t * 32 + c32] = FIRST ? sum : gd_old + sum;
     }
   }
   if (NEED_GX1) {
@@ -582,7 +681,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
       const float b2 = a.b2[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[r] = fmd_tanh(acc[r] + b2);
+        acc[r] = fmd_tanh_fast(acc[r] + b2);
         const int64_t row = row0 + tile_row(r, h);
         if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
       }
@@ -643,7 +742,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     const float b2 = a.b2[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      acc[r] = fmd_tanh(acc[r] + b2);
+      acc[r] = fmd_tanh_fast(acc[r] + b2);
       const int64_t row = row0 + tile_row(r, h);
       if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
     }
@@ -667,7 +766,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
       hk[k] = gemm_rows_streamed(cur, a.po[k], w, lane);
       const float bk = a.bo[k][col];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh(hk[k][r] + bk);
+      for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh_fast(hk[k][r] + bk);
       tile_to_lds(nxt, hk[k], w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
@@ -769,7 +868,8 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
 // one wave per molecule: forces from dE/dd of its pairs, energy from its beads (fixed order)
 __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pos,
                                                     const int64_t* __restrict__ mol_ptr,
-                                                    const uint32_t* __restrict__ paircode,
+                                                    const uint32_t* __restrict__ poi,
+                                                    const uint32_t* __restrict__ poj,
                                                     const float* __restrict__ pd,
                                                     const float* __restrict__ pgd,
                                                     const int32_t* __restrict__ npairs, int cap,
@@ -786,8 +886,8 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ po
   for (int p0 = 0; p0 < np; p0 += 64) {
     const int p = p0 + lane;
     if (p < np) {
-      const uint32_t code = paircode[(int64_t)m * cap + p];
-      const int i = code & 0xffff, j = code >> 16;
+      const int i = (int)(poi[(int64_t)m * cap + p] / (F * 4));
+      const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
       const float d = fmaxf(pd[(int64_t)m * cap + p], 1e-8f);
       const float s = pgd[(int64_t)m * cap + p] / d;
       const float dx = pos[3 * (a0 + j)] - pos[3 * (a0 + i)];
@@ -808,14 +908,16 @@ __global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ po
   if (lane == 0) energy[m] = e;
 }
 
+void* g_stamp_buffer = nullptr;  // set by fmd_debug_set_stamp_buffer (diagnostics, never in timed runs)
+
 int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct Workspace {
-  float *x, *gx, *gagg, *e_node, *pd, *pgd;
+  float *x, *gx, *gagg, *e_node, *pd, *pc, *pdc, *pgd;
   float* x1[8];
   float* t[8];
   float* slabs;
-  uint32_t* paircode;
+  uint32_t *poi, *poj;
   int32_t* npairs;
   int64_t total;
 };
@@ -853,8 +955,11 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   }
   w.slabs = (float*)take(nf * n_split);
   w.e_node = (float*)take(n_nodes * 4);
-  w.paircode = (uint32_t*)take(n_mol * cap * 4);
+  w.poi = (uint32_t*)take(n_mol * cap * 4);
+  w.poj = (uint32_t*)take(n_mol * cap * 4);
   w.pd = (float*)take(n_mol * cap * 4);
+  w.pc = (float*)take(n_mol * cap * 4);
+  w.pdc = (float*)take(n_mol * cap * 4);
   w.pgd = (float*)take(n_mol * cap * 4);
   w.npairs = (int32_t*)take(n_mol * 4);
   w.total = p - reinterpret_cast<char*>(base);
@@ -878,7 +983,8 @@ template <int KS0>
 int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, dim3 grid, size_t lds,
               hipStream_t s) {
   if (fwd) {
-    edge_fwd_kernel<KS0><<<grid, 256, lds, s>>>(ea);
+    if (ea.stamps) edge_fwd_kernel<KS0, true><<<grid, 256, lds, s>>>(ea);
+    else edge_fwd_kernel<KS0, false><<<grid, 256, lds, s>>>(ea);
   } else {
     const bool first = (l == L - 1), need = (l > 0);
     if (need && first) edge_bwd_kernel<KS0, true, true><<<grid, 256, lds, s>>>(ea);
@@ -891,8 +997,11 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
 
 template <int KS0>
 hipError_t set_edge_attrs(size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void*)edge_fwd_kernel<KS0>,
+  hipError_t e = hipFuncSetAttribute((const void*)edge_fwd_kernel<KS0, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_kernel<KS0, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -988,8 +1097,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 256, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
-                                                     desc->cutoff, (int)cap, ws.paircode, ws.pd,
-                                                     ws.npairs, status);
+                                                     desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
+                                                     ws.pc, ws.pdc, ws.npairs, status);
   ev_end();
   FMD_CHECK_LAUNCH();
 
@@ -1007,11 +1116,12 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   auto edge = [&](bool fwd, int l) -> int {
     const BlockOff o = block_off(PL, l);
     EdgeArgs ea;
-    ea.paircode = ws.paircode; ea.pd = ws.pd; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
+    ea.poi = ws.poi; ea.poj = ws.poj; ea.pd = ws.pd; ea.pc = ws.pc; ea.pdc = ws.pdc; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
     ea.mol_ptr = mol_ptr; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
     ea.p0 = pk + o.p0; ea.b0 = pk + o.b0; ea.p1 = pk + o.p1; ea.p1t = pk + o.p1t;
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
+    ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);
     if (ks0 <= 16) return run_edges<16>(desc, fwd, l, L, ea, egrid, lds_edge, s);
     if (ks0 <= 25) return run_edges<25>(desc, fwd, l, L, ea, egrid, lds_edge, s);
     return run_edges<32>(desc, fwd, l, L, ea, egrid, lds_edge, s);
@@ -1080,7 +1190,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   }
   ev_begin();
   finish_kernel<<<(unsigned)n_mol, 64, 3 * max_beads_per_mol * sizeof(float), s>>>(
-      pos, mol_ptr, ws.paircode, ws.pd, ws.pgd, ws.npairs, (int)cap, ws.e_node, energy, forces);
+      pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, ws.npairs, (int)cap, ws.e_node, energy, forces);
   ev_end();
   FMD_CHECK_LAUNCH();
   return FMD_OK;
@@ -1094,6 +1204,13 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
                                         int32_t* status, void* stream) {
   return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
                     max_pairs_per_mol, energy, forces, workspace, status, stream, nullptr);
+}
+
+// Diagnostic hook: device buffer of [workgroups][4 waves][6 phases] uint64 cycle totals written by
+// the stamped build of the forward pair kernel; NULL (default) selects the normal kernels.
+extern "C" int fmd_debug_set_stamp_buffer(void* device_buffer) {
+  g_stamp_buffer = device_buffer;
+  return FMD_OK;
 }
 
 extern "C" int fmd_schnet_kernel_count(const fmd_schnet_desc* desc) {

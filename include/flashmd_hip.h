@@ -220,6 +220,10 @@ int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* pack
                                    void* workspace, int32_t* status, void* stream, void** events,
                                    int64_t n_events);
 
+/* Diagnostics only: device buffer [workgroups][4][6] of uint64 receiving per-phase cycle totals from
+ * the stamped build of the forward pair kernel (NULL restores the normal kernels). */
+int fmd_debug_set_stamp_buffer(void* device_buffer);
+
 /* ---------------------------------------------------------------------------------------------
  * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).
  *   pre : v += .5 dt f/m ; x += .5 dt v ; v = vscale v + noisescale sqrt(1/(beta m)) * noise ; x += .5 dt v
