@@ -57,10 +57,15 @@ def shard_range(n_mol: int, rank: int, world: int):
 
 class LangevinSimulation:
     """Minimal BAOAB loop over one rank's batch (reference simulation/langevin.py:21-312 and the
-    loop of simulation/base.py:501-649), forces from ``force_fn(pos) -> (energy[B], forces[N,3])``."""
+    loop of simulation/base.py:501-649), forces from ``force_fn(pos) -> (energy[B], forces[N,3])``.
+    ``use_hip`` (default: the MLCG_USE_* gates) selects the fused HIP halves; with the gates off
+    (--disable_optim) the same update runs as plain torch ops, which is what runs on the CPU."""
 
     def __init__(self, force_fn, pos, masses, beta_mol, n_atoms: int, dt: float = 0.004,
-                 friction: float = 1.0, seed: int = 103838):
+                 friction: float = 1.0, seed: int = 103838, use_hip: Optional[bool] = None):
+        from . import schnet
+
+        self.use_hip = schnet.any_hip_gate_on() if use_hip is None else use_hip
         self.force_fn, self.dt, self.friction, self.n_atoms = force_fn, dt, friction, n_atoms
         self.x = pos.detach().clone().contiguous()
         self.masses = masses.contiguous()
@@ -76,10 +81,22 @@ class LangevinSimulation:
 
     def timestep(self):
         self.noise.normal_(generator=self.rng)  # reference langevin.py:146
-        langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt,
-                     self.friction)
+        if self.use_hip:
+            langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt,
+                         self.friction)
+            self.energy, self.f = self.force_fn(self.x)
+            langevin_post(self.v, self.f, self.masses, self.dt)
+            return
+        # PyTorch path (reference simulation/langevin.py:136-170)
+        dt, m = self.dt, self.masses[:, None]
+        vscale = math.exp(-self.friction * dt)
+        noisescale = math.sqrt(1.0 - vscale * vscale)
+        v = self.v + 0.5 * dt * self.f / m
+        x = self.x + v * dt * 0.5
+        v = v * vscale + noisescale * (torch.sqrt(1.0 / self.beta_node / self.masses)[:, None] * self.noise)
+        self.x = x + v * dt * 0.5
         self.energy, self.f = self.force_fn(self.x)
-        langevin_post(self.v, self.f, self.masses, self.dt)
+        self.v = v + 0.5 * dt * self.f / m
 
     def simulate(self, n_timesteps: int, subroutine=None, interval: int = 0):
         """Runs the loop and returns timestep*mol/s measured over the second half
@@ -88,12 +105,137 @@ class LangevinSimulation:
 
         half = n_timesteps // 2
         t0 = None
+        sync = torch.cuda.synchronize if self.x.is_cuda else (lambda: None)
         for t in range(n_timesteps):
             if t == half:
-                torch.cuda.synchronize()
+                sync()
                 t0 = time.perf_counter()
             self.timestep()
             if subroutine is not None and interval and (t + 1) % interval == 0:
                 subroutine(self)
-        torch.cuda.synchronize()
+        sync()
         return (n_timesteps - half) * self.n_sims / (time.perf_counter() - t0)
+
+
+def pt_pairs(n_betas: int, even: bool):
+    """Neighbouring temperature pairs proposed in one exchange attempt: (0,1),(2,3).. on even
+    attempts, (1,2),(3,4).. on odd ones (reference simulation/parallel_tempering.py:256-284,349-366)."""
+    start = 0 if even else 1
+    return [(a, a + 1) for a in range(start, n_betas - 1, 2)]
+
+
+def pt_accept(u_a, u_b, beta_a: float, beta_b: float, rand_u):
+    """Metropolis criterion of reference parallel_tempering.py:393-394:
+    accept where rand < exp((U_a - U_b) (beta_a - beta_b))."""
+    return rand_u < torch.exp((u_a - u_b) * (beta_a - beta_b))
+
+
+class DistributedReplicaExchange:
+    """Parallel tempering with ONE temperature per rank (BASELINE config 5): rank r simulates
+    ``n_indep`` replicas at betas[r]; every ``interval`` steps neighbouring ranks attempt to swap
+    replica k of one with replica k of the other (reference simulation/parallel_tempering.py:368-481,
+    where all temperatures live in one batch).
+
+    The force path never communicates.  An exchange attempt is point-to-point between the two
+    partner ranks only (torch.distributed send/recv = RCCL over the direct xGMI link on GPUs, gloo
+    on CPU): energies first (n_indep floats), then positions+velocities of the batch (fixed size,
+    <= 0.83 MB at 128 x 269 beads), applied where the pair was accepted.  Both partners draw the
+    same uniform numbers from a counter-based CPU generator keyed by (seed, attempt, lower rank),
+    so they reach the same decision without a second message (the reference draws from the global
+    CPU RNG, parallel_tempering.py:394)."""
+
+    def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert len(betas) == self.world, "one beta per rank"
+        self.betas = [float(b) for b in betas]
+        self.n_indep, self.n_atoms, self.seed = n_indep, n_atoms, seed
+        self.attempt = 0
+        self.accepted = torch.zeros(self.world, dtype=torch.int64)   # with the upper neighbour
+        self.attempted = torch.zeros(self.world, dtype=torch.int64)
+
+    def partner(self, even: bool) -> Optional[int]:
+        for a, b in pt_pairs(self.world, even):
+            if self.rank == a:
+                return b
+            if self.rank == b:
+                return a
+        return None
+
+    def __call__(self, sim: "LangevinSimulation"):
+        even = self.attempt % 2 == 0
+        peer = self.partner(even)
+        attempt = self.attempt
+        self.attempt += 1
+        if peer is None:
+            return
+        dist = self.dist
+        lo, hi = min(self.rank, peer), max(self.rank, peer)
+        # 1. energies of the partner's replicas
+        u_mine = sim.energy.detach().contiguous()
+        u_peer = torch.empty_like(u_mine)
+        ops = [dist.P2POp(dist.isend, u_mine, peer, self.group), dist.P2POp(dist.irecv, u_peer, peer, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        # 2. the same decision on both sides (a = lower rank of the pair)
+        g = torch.Generator().manual_seed((self.seed * 1000003 + attempt) * 4099 + lo)
+        rand_u = torch.rand(self.n_indep, generator=g).to(u_mine.device)
+        u_a, u_b = (u_mine, u_peer) if self.rank == lo else (u_peer, u_mine)
+        acc = pt_accept(u_a, u_b, self.betas[lo], self.betas[hi], rand_u)
+        # 3. positions and velocities of the whole batch cross the link once, each way
+        payload = torch.stack([sim.x, sim.v]).contiguous()
+        incoming = torch.empty_like(payload)
+        ops = [dist.P2POp(dist.isend, payload, peer, self.group), dist.P2POp(dist.irecv, incoming, peer, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
+        #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
+        mask = acc.repeat_interleave(self.n_atoms)[:, None]
+        scale = math.sqrt(self.betas[self.rank] / self.betas[peer])
+        sim.x = torch.where(mask, incoming[0], sim.x).contiguous()
+        sim.v = torch.where(mask, incoming[1] * scale, sim.v).contiguous()
+        if self.rank == lo:
+            self.accepted[lo] += int(acc.sum())
+            self.attempted[lo] += self.n_indep
+        # forces/energies of the swapped replicas belong to the other temperature's coordinates:
+        # re-evaluate so the next B half-kick uses forces at the new positions (the reference keeps
+        # stale forces until the next timestep's force call; re-evaluating is the conservative choice)
+        sim.energy, sim.f = sim.force_fn(sim.x)
+
+    def acceptance(self):
+        """Per-pair acceptance counts reduced to every rank (export-time only)."""
+        acc, att = self.accepted.clone(), self.attempted.clone()
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        acc, att = acc.to(dev), att.to(dev)
+        self.dist.all_reduce(acc, group=self.group)
+        self.dist.all_reduce(att, group=self.group)
+        return acc.cpu(), att.cpu()
+
+
+class LocalReplicaExchange:
+    """All temperatures in one batch on one GPU (the reference's layout: beta-major blocks of
+    ``n_indep`` replicas, parallel_tempering.py:204-220); accepted pairs are swapped in place by the
+    HIP kernel behind fmd_pt_swap_local."""
+
+    def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0):
+        self.betas, self.n_indep, self.n_atoms = [float(b) for b in betas], n_indep, n_atoms
+        self.gen = torch.Generator().manual_seed(seed)
+        self.attempt = 0
+
+    def __call__(self, sim: "LangevinSimulation"):
+        even = self.attempt % 2 == 0
+        self.attempt += 1
+        pairs = pt_pairs(len(self.betas), even)
+        if not pairs:
+            return
+        dev = sim.x.device
+        k = torch.arange(self.n_indep)
+        mol_a = torch.cat([a * self.n_indep + k for a, _ in pairs]).to(dev)
+        mol_b = torch.cat([b * self.n_indep + k for _, b in pairs]).to(dev)
+        beta = sim.beta_mol
+        p = torch.exp((sim.energy[mol_a] - sim.energy[mol_b]) * (beta[mol_a] - beta[mol_b]))
+        acc = (torch.rand(p.numel(), generator=self.gen).to(dev) < p).to(torch.uint8)
+        pt_swap_local(sim.x, sim.v, mol_a, mol_b, acc, beta, self.n_atoms)
+        sim.energy, sim.f = sim.force_fn(sim.x)
