@@ -123,7 +123,7 @@ def main():
             if n_.endswith("bias"):
                 prm.uniform_(-0.1, 0.1)
     model = model.to(dev).eval()
-    eng = engine.FusedSchNetEngine(model)
+    eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")))
     names = eng.kernel_names()
 
     # every rank owns its own molecules (different seeds per rank): embarrassingly parallel shards

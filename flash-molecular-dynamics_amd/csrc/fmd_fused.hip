@@ -16,6 +16,8 @@
 //    the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice GEMMs), so the only
 //    per-pair quantity that reaches HBM is one float (dE/dd) per pair.
 #include <string.h>
+#include <type_traits>
+#include <stdlib.h>
 
 #include "fmd_common.h"
 
@@ -301,6 +303,16 @@ struct EdgeArgs {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// compile-time unrolled loop: the body receives std::integral_constant<int, I> (true constants keep
+// every register-array index static, so nothing is demoted to scratch)
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int KS0, bool STAMP>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -456,6 +468,228 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
   for (int i = tid * 4; i < n * F; i += 1024)
+    *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+}
+
+// =================================================================================================
+// Wave-specialised forward pair kernel: 8 waves per workgroup, two per SIMD.
+//   waves 0-3 (consumers): own the 32-feature slices -- L1 MFMAs, x1 gathers, aggregate update in LDS
+//   waves 4-7 (producers): rbf values on the VALU, L0 MFMAs, tanh, hidden tile -> LDS
+// A single wave per SIMD is instruction-issue bound here (about 800 non-MFMA instructions per 89 MFMAs
+// per tile); two waves per SIMD give the MFMA pipe a second instruction stream to overlap with, and the
+// split keeps the LDS footprint of the 4-wave design (one hidden tile + one aggregate).
+// Per tile two workgroup barriers:  A(t) "hidden(t) visible", B(t) "hidden(t) consumed".
+// =================================================================================================
+struct SegRegs {              // consumer state of one 32-entry tile, register r = 4q + e <-> entry 8q+4h+e
+  uint32_t oi[4];             // centre row byte offset of segment q (+ this lane's column)
+  uint32_t oj[16];            // neighbour row byte offsets
+  float cr[16];               // C(d) per entry
+  float xi[4], xj[16];        // gathered x1[centre], x1[neighbour] (this lane's feature)
+};
+
+template <int KS0, bool STAMP>
+__global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hid = smem;                 // [32][LDA]
+  float* agg = smem + TILE_FLOATS;   // [n][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const bool producer = wave >= 4;   // wave-uniform
+  const int w = wave & 3;            // feature slice
+  const int m = blockIdx.y, split = blockIdx.x;
+  const int64_t a0 = a.mol_ptr[m];
+  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int np = a.npairs[m];
+  for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const int ntiles = (np + 31) >> 5;
+  const int S = a.n_split;
+  const int last_base = (ntiles - 1) * 32;
+  __syncthreads();
+  if (split < ntiles) {  // uniform over the workgroup
+    if (producer) {
+      // ------------------------------------------------------------------ producer waves
+      float w0[KS0], cen[KS0], b0r[16];
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) w0[s] = a.p0[(w * 32 + s) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) cen[s] = a.centers[2 * s + h];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+      float d_n = pdist[min(split * 32, last_base) + c32], c_n = pcut[min(split * 32, last_base) + c32];
+      auto compute = [&](int t_next) {  // hidden^T slice of the tile whose meta is in (d_n, c_n)
+        const float d = d_n, C = c_n;
+        const int nb = min(t_next * 32, last_base);
+        d_n = pdist[nb + c32];
+        c_n = pcut[nb + c32];
+        // rbf values first (independent VALU chains pipeline; interleaving them one-to-one with the
+        // dependent MFMA chain costs ~116 cycles per step instead of 64), then the MFMA chain
+        float bval[KS0];
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) {
+          const float diff = d - cen[s];
+          bval[s] = __expf(a.gamma * diff * diff) * C;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s = 0; s < KS0; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[s], bval[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = fmd_tanh_fast(acc[r] + b0r[r]);
+        // pin the whole computation in front of the barrier that follows (it has no memory side
+        // effect, so the scheduler would otherwise sink it behind the barrier, onto the critical path)
+        asm volatile("" : "+v"(acc));
+        return acc;
+      };
+      auto put = [&](const f32x16& v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(hid + c32 * LDA + 32 * w + 8 * q + 4 * h) =
+              f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      };
+      __builtin_amdgcn_s_setprio(1);  // the short MFMA chain of the producers goes first on the shared pipe
+      put(compute(split + S));
+      __syncthreads();  // A(first)
+      for (int t = split; t < ntiles; t += S) {
+        const f32x16 hv = compute(t + 2 * S);  // tile t+S, while the consumers contract tile t
+        __syncthreads();                       // B(t)
+        put(hv);
+        __syncthreads();                       // A(t+S)
+      }
+    } else {
+      // ------------------------------------------------------------------ consumer waves
+      float w1[64];
+#pragma unroll
+      for (int s = 0; s < 64; ++s) w1[s] = a.p1[(w * 64 + s) * 64 + lane];
+      const uint32_t col4 = (uint32_t)(32 * w + c32) * 4u;
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      char* aggb = reinterpret_cast<char*>(agg);
+      SegRegs X;
+      // meta of the tile being loaded into X (flat scalars, static indices: stays in registers)
+      uint32_t oj_m[16], oi_m[4];
+      float cr_m[16];
+      float Wq[4], vj[4], cval = 0.f, si = 0.f, so = 0.f;  // aggregate-update state of one segment
+      // side work of region gap `i` for the tile whose meta/gathers go into X (entry base `base`)
+      // and the aggregate update of the previous tile (filter slice fl_p)
+      auto side_fetch = [&](auto ic, int base) {
+        constexpr int i = decltype(ic)::value;
+        // ---- meta loads of the new tile: gaps 0..11
+        if constexpr (i < 4) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * i + 4 * h);
+          oj_m[4 * i] = v[0]; oj_m[4 * i + 1] = v[1]; oj_m[4 * i + 2] = v[2]; oj_m[4 * i + 3] = v[3];
+        } else if constexpr (i < 8) {
+          constexpr int k = i - 4;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(pcut + base + 8 * k + 4 * h);
+          cr_m[4 * k] = v[0]; cr_m[4 * k + 1] = v[1]; cr_m[4 * k + 2] = v[2]; cr_m[4 * k + 3] = v[3];
+        } else if constexpr (i < 12) {
+          oi_m[i - 8] = poi[base + 8 * (i - 8) + 4 * h];
+        }
+      };
+      auto side_msg = [&](auto ic, const f32x16& fl_p) {
+        constexpr int i = decltype(ic)::value;
+        // ---- aggregate update of the previous tile (X still holds it): gaps 2..25, segment q in
+        //      four steps (one centre, distinct neighbours: plain read-modify-write)
+        if constexpr (i >= 2 && i < 26) {
+          constexpr int q = (i - 2) / 6, ph = (i - 2) % 6;
+          if constexpr (ph == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              Wq[e] = fl_p[4 * q + e] * X.cr[4 * q + e];
+              vj[e] = *reinterpret_cast<const float*>(aggb + X.oj[4 * q + e]);
+            }
+            cval = *reinterpret_cast<const float*>(aggb + X.oi[q]);
+          } else if constexpr (ph == 1) {
+            si = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) si += X.xj[4 * q + e] * Wq[e];
+            so = __shfl_xor(si, 32, 64);
+          } else if constexpr (ph == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              *reinterpret_cast<float*>(aggb + X.oj[4 * q + e]) = vj[e] + X.xi[q] * Wq[e];
+          } else if constexpr (ph == 3) {
+            // both halves store the same value to the same address
+            *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + (si + so);
+          }
+        }
+      };
+      auto side_fill = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        // ---- X <- new tile: offsets (gaps 30..33), x1 gathers (gaps 34..53)
+        if constexpr (i >= 30 && i < 34) {
+          constexpr int q = i - 30;
+          X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+            X.cr[4 * q + e] = cr_m[4 * q + e];
+          }
+        }
+        if constexpr (i >= 34 && i < 38) X.xi[i - 34] = *reinterpret_cast<const float*>(x1b + X.oi[i - 34]);
+        if constexpr (i >= 38 && i < 54) X.xj[i - 38] = *reinterpret_cast<const float*>(x1b + X.oj[i - 38]);
+      };
+      // prologue: X <- tile `split` (its aggregate update runs, with a zero filter, inside region(split))
+      f32x16 fl_prev = zero16();
+      {
+        const int base = min(split * 32, last_base);
+        static_for<0, 12>([&](auto ic) { side_fetch(ic, base); });
+        static_for<30, 54>([&](auto ic) { side_fill(ic); });
+      }
+      unsigned long long t_region = 0, t_bb = 0, t_ba = 0, tprev = 0;
+      __syncthreads();  // A(first)
+      if (STAMP) tprev = __builtin_readcyclecounter();
+      for (int t = split; t < ntiles; t += S) {
+        // region(t): 64 L1 MFMAs of tile t; in their shadows the aggregate update of tile t-S (held in
+        // X, fl_prev), then X is refilled with tile t: meta loads, offsets, x1 gathers.
+        const int base = min(t * 32, last_base);
+        f32x16 fl = zero16();
+        const float* ap = hid + c32 * LDA + 64 * h;
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(ap);
+        f32x4 a4n = a4;
+        static_for<0, 64>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr ((i & 3) == 0 && i < 60) a4n = *reinterpret_cast<const f32x4*>(ap + i + 4);
+          fl = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i & 3], w1[i], fl, 0, 0, 0);
+          side_fetch(ic, base);
+          side_msg(ic, fl_prev);
+          side_fill(ic);
+          if constexpr ((i & 3) == 3) a4 = a4n;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        fl_prev = fl;
+        if (STAMP) {
+          asm volatile("" : "+v"(fl_prev));
+          const unsigned long long now = __builtin_readcyclecounter();
+          t_region += now - tprev;
+          tprev = now;
+        }
+        __syncthreads();  // B(t): hidden tile consumed
+        if (STAMP) {
+          const unsigned long long now = __builtin_readcyclecounter();
+          t_bb += now - tprev;
+          tprev = now;
+        }
+        __syncthreads();  // A(t+S)
+        if (STAMP) {
+          const unsigned long long now = __builtin_readcyclecounter();
+          t_ba += now - tprev;
+          tprev = now;
+        }
+      }
+      if (STAMP && lane == 0) {
+        unsigned long long* o = a.stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8;
+        o[0] = t_region; o[1] = t_bb; o[2] = t_ba;
+        for (int k = 3; k < 8; ++k) o[k] = 0;
+      }
+      // the last tile's aggregate update
+      static_for<2, 26>([&](auto ic) { side_msg(ic, fl_prev); });
+    }
+  }
+  __syncthreads();
+  float* out = a.slabs + split * a.slab_stride + a0 * F;
+  for (int i = tid * 4; i < n * F; i += 2048)
     *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
 }
 
@@ -983,8 +1217,13 @@ template <int KS0>
 int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, dim3 grid, size_t lds,
               hipStream_t s) {
   if (fwd) {
-    if (ea.stamps) edge_fwd_kernel<KS0, true><<<grid, 256, lds, s>>>(ea);
-    else edge_fwd_kernel<KS0, false><<<grid, 256, lds, s>>>(ea);
+    if (getenv("FMD_FWD_4WAVE")) {
+      if (ea.stamps) edge_fwd_kernel<KS0, true><<<grid, 256, lds, s>>>(ea);
+      else edge_fwd_kernel<KS0, false><<<grid, 256, lds, s>>>(ea);
+    } else {
+      if (ea.stamps) edge_fwd_ws_kernel<KS0, true><<<grid, 512, lds, s>>>(ea);
+      else edge_fwd_ws_kernel<KS0, false><<<grid, 512, lds, s>>>(ea);
+    }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
     if (need && first) edge_bwd_kernel<KS0, true, true><<<grid, 256, lds, s>>>(ea);
@@ -1001,6 +1240,12 @@ hipError_t set_edge_attrs(size_t lds) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_fwd_kernel<KS0, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,
