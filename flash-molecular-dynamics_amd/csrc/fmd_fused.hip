@@ -26,7 +26,7 @@ namespace {
 constexpr int F = 128;            // hidden = filters
 constexpr int LDA = 132;          // LDS row stride (floats) of a 32 x 128 operand tile
 constexpr int TILE_FLOATS = 32 * LDA;
-constexpr int MAX_LDS_ROWS = 286; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
+constexpr int MAX_LDS_ROWS = 284; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
 constexpr int SLICE = 4 * 64 * 64;  // floats of one packed 128x128 operand ([wave][k-step][lane])
 constexpr int P0_FLOATS = 4 * 32 * 64;
 
@@ -35,11 +35,14 @@ constexpr int P0_FLOATS = 4 * 32 * 64;
 // ---------------------------------------------------------------------------------------------
 struct BlockOff {
   int64_t p0, b0, p1, p1t, l1, l1t, l2, b2, l2t, l3, b3, l3t;
+  int64_t q0h, q0l, q1h, q1l, q1th, q1tl;  // fp16 hi/lo split operands of the filter network
 };
 struct PackLayout {
   int64_t emb, centers, blocks, block_stride, outs, out_stride, total;
 };
-constexpr int64_t BLOCK_FLOATS = P0_FLOATS + F + 8 * (int64_t)SLICE + 2 * F;
+constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // [wave][k-step of 16][lane] x 8 halves (16 B), K padded to 64
+constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
+constexpr int64_t BLOCK_FLOATS = P0_FLOATS + F + 8 * (int64_t)SLICE + 2 * F + 2 * Q0_FLOATS + 4 * Q1_FLOATS;
 constexpr int64_t OUT_FLOATS = 2 * (int64_t)SLICE + F;
 
 PackLayout pack_layout(const fmd_schnet_desc* d) {
@@ -68,6 +71,12 @@ BlockOff block_off(const PackLayout& L, int l) {
   o.l3 = p; p += SLICE;
   o.b3 = p; p += F;
   o.l3t = p; p += SLICE;
+  o.q0h = p; p += Q0_FLOATS;
+  o.q0l = p; p += Q0_FLOATS;
+  o.q1h = p; p += Q1_FLOATS;
+  o.q1l = p; p += Q1_FLOATS;
+  o.q1th = p; p += Q1_FLOATS;
+  o.q1tl = p; p += Q1_FLOATS;
   return o;
 }
 
@@ -83,6 +92,26 @@ void pack_slice(float* dst, const float* M, int n_out, int n_k, bool transposed)
         if (o < n_out && k < n_k) v = transposed ? M[(int64_t)k * n_out + o] : M[(int64_t)o * n_k + k];
         dst[(w * 64 + s) * 64 + l] = v;
       }
+}
+// fp16 hi/lo split of an operand for v_mfma_f32_32x32x16_f16: x ~ hi + lo / 2048 with hi = f16(x),
+// lo = f16((x - hi) * 2048).  Record (w, s, lane) holds the 8 halves M[32w + (lane&31)][16s + 8(lane>>5) + j]
+// (the A-operand and the B-operand fragment of that instruction index their matrix the same way).
+void pack_split(float* dst_hi, float* dst_lo, const float* M, int n_out, int n_k, int n_steps,
+                bool transposed) {
+  _Float16* hi = reinterpret_cast<_Float16*>(dst_hi);
+  _Float16* lo = reinterpret_cast<_Float16*>(dst_lo);
+  for (int w = 0; w < 4; ++w)
+    for (int s = 0; s < n_steps; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int o = 32 * w + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
+          float v = 0.f;
+          if (o < n_out && k < n_k) v = transposed ? M[(int64_t)k * n_out + o] : M[(int64_t)o * n_k + k];
+          const _Float16 h = (_Float16)v;
+          const int64_t idx = (((int64_t)w * n_steps + s) * 64 + l) * 8 + j;
+          hi[idx] = h;
+          lo[idx] = (_Float16)((v - (float)h) * 2048.0f);
+        }
 }
 // filter layer 0 as the A operand of hidden^T = W0 rbf^T: lane l, step s: f0_w[32w+(l&31)][2s+(l>>5)]
 void pack_p0(float* dst, const float* f0_w, int n_rbf) {
@@ -293,6 +322,7 @@ struct EdgeArgs {
   const float* b0;
   const float* p1;         // packed filter layer 1 (B operand)
   const float* p1t;        // packed filter layer 1 transposed (A operand of u)
+  const float *q0h, *q0l, *q1h, *q1l, *q1th, *q1tl;  // fp16 hi/lo split operands (16-byte records)
   const float* centers;    // [64]
   float* slabs;            // [n_split][N,128] partial aggregates (fwd: agg, bwd: gx1)
   int64_t slab_stride;
@@ -691,6 +721,528 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
   float* out = a.slabs + split * a.slab_stride + a0 * F;
   for (int i = tid * 4; i < n * F; i += 2048)
     *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+}
+
+// =================================================================================================
+// fp32-grade forward pair kernel on the fp16 MFMA (v_mfma_f32_32x32x16_f16) with split operands:
+// every operand x is carried as hi = f16(x), lo = f16((x - hi) * 2048) and a product a.b is
+// a_hi.b_hi + (a_hi.b_lo + a_lo.b_hi) / 2048, accumulated in fp32 (two accumulators).  The dropped
+// a_lo.b_lo term is 2^-22 relative: measured error of a 128-deep contraction 2e-7, the same as the
+// fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
+// edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
+// =================================================================================================
+constexpr int LDH = 136;                       // halves per row of an fp16 LDS tile (272 B)
+constexpr int TILE_H_BYTES = 32 * LDH * 2;     // one fp16 tile
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+
+// 8 fp32 values -> hi / lo fp16 fragments
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
+    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
+    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
+    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
+    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
+  }
+}
+__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
+    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
+    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
+    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
+    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
+  }
+}
+// acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
+__device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
+                                           const f16x8& bl, f32x16& acc1, f32x16& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+}
+
+template <int NS0>  // k-steps of 16 covering the rbf index (ceil(R / 16))
+__global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
+  _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
+  float* agg = smem + TILE_FLOATS + 128;                         // [n][128] (same offset as the other kernels)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const bool producer = wave >= 4;   // wave-uniform
+  const int w = wave & 3;            // feature slice
+  const int m = blockIdx.y, split = blockIdx.x;
+  const int64_t a0 = a.mol_ptr[m];
+  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int np = a.npairs[m];
+  for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const int ntiles = (np + 31) >> 5;
+  const int S = a.n_split;
+  const int last_base = (ntiles - 1) * 32;
+  __syncthreads();
+  if (split < ntiles) {  // uniform over the workgroup
+    if (producer) {
+      // ------------------------------------------------------------------ producer waves
+      f16x8 a0h[NS0], a0l[NS0];
+      float cen[8 * NS0], b0r[16];
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) {
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cen[8 * s + j] = a.centers[16 * s + 8 * h + j];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+      float d_n = pdist[min(split * 32, last_base) + c32], c_n = pcut[min(split * 32, last_base) + c32];
+      f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
+      auto compute = [&](int t_next) {
+        const float d = d_n, C = c_n;
+        const int nb = min(t_next * 32, last_base);
+        d_n = pdist[nb + c32];
+        c_n = pcut[nb + c32];
+        f32x16 acc1 = zero16(), acc2 = zero16();
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float diff = d - cen[8 * s + j];
+            x[j] = __expf(a.gamma * diff * diff) * C;
+          }
+          f16x8 bh, bl;
+          split8(x, bh, bl);
+          mfma_split(a0h[s], a0l[s], bh, bl, acc1, acc2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            t4[e] = fmd_tanh_fast(acc1[4 * q + e] + acc2[4 * q + e] * SPLIT_INV + b0r[4 * q + e]);
+          split4(t4, hh[q], hl[q]);
+        }
+        // pin the computation in front of the barrier that follows
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
+      };
+      auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+          *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+        }
+      };
+      compute(split + S);
+      put();
+      __syncthreads();  // A(first)
+      for (int t = split; t < ntiles; t += S) {
+        compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        __syncthreads();     // B(t)
+        put();
+        __syncthreads();     // A(t+S)
+      }
+    } else {
+      // ------------------------------------------------------------------ consumer waves
+      f16x8 b1h[8], b1l[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
+        b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+      }
+      const uint32_t col4 = (uint32_t)(32 * w + c32) * 4u;
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      char* aggb = reinterpret_cast<char*>(agg);
+      SegRegs X;
+      uint32_t oj_m[16], oi_m[4];
+      float cr_m[16];
+      auto fetch_meta = [&](int t) {
+        const int base = min(t * 32, last_base);
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+          oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
+          const f32x4 c = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
+          cr_m[4 * q] = c[0]; cr_m[4 * q + 1] = c[1]; cr_m[4 * q + 2] = c[2]; cr_m[4 * q + 3] = c[3];
+          oi_m[q] = poi[base + 8 * q + 4 * h];
+        });
+      };
+      auto fill = [&]() {  // X <- fetched tile: offsets and x1 gathers
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+            X.cr[4 * q + e] = cr_m[4 * q + e];
+          }
+        });
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+        });
+        static_for<0, 16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          X.xj[r] = *reinterpret_cast<const float*>(x1b + X.oj[r]);
+        });
+      };
+      // aggregate update: segment q has one centre and distinct neighbours -> plain read-modify-write
+      auto message = [&](const f32x16& fl) {
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          float Wq[4], vj[4];
+          float si = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            Wq[e] = fl[4 * q + e] * X.cr[4 * q + e];
+            vj[e] = *reinterpret_cast<const float*>(aggb + X.oj[4 * q + e]);
+            si += X.xj[4 * q + e] * Wq[e];
+          }
+          const float cval = *reinterpret_cast<const float*>(aggb + X.oi[q]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<float*>(aggb + X.oj[4 * q + e]) = vj[e] + X.xi[q] * Wq[e];
+          si += __shfl_xor(si, 32, 64);
+          // both halves store the same value to the same address
+          *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + si;
+        });
+      };
+      fetch_meta(split);
+      fill();
+      fetch_meta(split + S);
+      __syncthreads();  // A(first)
+      for (int t = split; t < ntiles; t += S) {
+        // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16(), acc2 = zero16();
+        {
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ph + 16 * s);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+            mfma_split(ah, al, b1h[s], b1l[s], acc1, acc2);
+          }
+        }
+        f32x16 fl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fl[r] = acc1[r] + acc2[r] * SPLIT_INV;
+        asm volatile("" : "+v"(fl));  // L1 complete (its LDS reads with it) before the barrier
+        __syncthreads();  // B(t): hidden tiles consumed
+        message(fl);      // tile t (X holds its gathers)
+        fill();           // X <- tile t+S (meta fetched one tile ago)
+        fetch_meta(t + 2 * S);
+        __syncthreads();  // A(t+S)
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.slabs + split * a.slab_stride + a0 * F;
+  for (int i = tid * 4; i < n * F; i += 2048)
+    *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+}
+
+// =================================================================================================
+// fp32-grade backward pair kernel, split-operand fp16 MFMA, wave specialised (see edge_fwd_split_kernel).
+//   producers (waves 4-7): rbf and d(rbf)/dd, L0 and z' = W0 . rbf' (12 + 12 MFMA), tanh, hidden tiles
+//                          -> LDS; later u = gW . W1 (24 MFMA) and the per-pair reduction to dE/dd
+//   consumers (waves 0-3): L1 recomputed (24 MFMA), gathers of x1 / d(agg) rows, the gW tile -> LDS,
+//                          gx1 aggregate update in LDS
+// One LDS region carries the hidden tiles (fp16 hi, lo) and then the gW tile (u32 = hi | lo << 16).
+// Barriers per tile: A hidden visible, B hidden consumed, C gW visible, D gW consumed + partial sums.
+// =================================================================================================
+struct SegRegsB {             // consumer state of one tile (register r = 4q + e <-> entry 8q+4h+e)
+  uint32_t oi[4], oj[16];
+  float cr[16];
+  float xi[4], xj[16], gi[4], gj[16];
+};
+
+template <int NS0, bool NEED_GX1, bool FIRST>
+__global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
+  _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
+  uint32_t* gwt = reinterpret_cast<uint32_t*>(smem);             // [32][LDA] packed (hi | lo << 16), same region
+  float* red = smem + TILE_FLOATS + 128;                         // [4][32]
+  float* cen_l = red + 128;                                      // [64] rbf centres
+  float* gx1 = cen_l + 64;                                       // [n][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const bool producer = wave >= 4;   // wave-uniform
+  const int w = wave & 3;            // feature slice
+  const int m = blockIdx.y, split = blockIdx.x;
+  const int64_t a0 = a.mol_ptr[m];
+  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int np = a.npairs[m];
+  if (NEED_GX1)
+    for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 64) cen_l[tid] = a.centers[tid];
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const float* pdcut = a.pdc + (int64_t)m * a.cap;
+  float* pgd = a.pgd + (int64_t)m * a.cap;
+  const int ntiles = (np + 31) >> 5;
+  const int S = a.n_split;
+  const int last_base = (ntiles - 1) * 32;
+  __syncthreads();
+  if (split < ntiles) {  // uniform over the workgroup
+    if (producer) {
+      // ------------------------------------------------------------------ producer waves
+      f16x8 a0h[NS0], a0l[NS0], wth[8], wtl[8];
+      float b0r[16];
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) {
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
+        wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + s) * 64 + lane];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+      // meta of the tile to stage next (lane = pair view)
+      float d_n, c_n, dc_n, gd_n = 0.f;
+      auto fetch = [&](int t) {
+        const int base = min(t * 32, last_base);
+        d_n = pdist[base + c32];
+        c_n = pcut[base + c32];
+        dc_n = pdcut[base + c32];
+        if (!FIRST) gd_n = pgd[base + c32];
+      };
+      // staged tile ("nx") and tile whose reduction is pending ("cu")
+      f16x4 hh[4], hl[4];
+      float hr_nx[16], k1_nx[16], C_nx = 0.f, dC_nx = 0.f, gd_nx = 0.f;
+      float hr_cu[16], k1_cu[16], C_cu = 0.f, dC_cu = 0.f, gd_cu = 0.f;
+      auto compute = [&](int t_fetch) {
+        const float d = d_n, C = c_n, dC = dc_n;
+        C_nx = C; dC_nx = dC; gd_nx = gd_n;
+        fetch(t_fetch);
+        f32x16 z1 = zero16(), z2 = zero16(), p1 = zero16(), p2 = zero16();
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) {
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
+          float x[8], xp[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float diff = d - (j < 4 ? c0[j & 3] : c1[j & 3]);
+            const float raw = __expf(a.gamma * diff * diff);
+            x[j] = raw * C;
+            xp[j] = raw * (2.0f * a.gamma * diff * C + dC);
+          }
+          f16x8 bh, bl, ph, pl;
+          split8(x, bh, bl);
+          split8(xp, ph, pl);
+          mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
+          mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float hv = fmd_tanh_fast(z1[r] + z2[r] * SPLIT_INV + b0r[r]);
+            t4[e] = hv;
+            hr_nx[r] = hv;
+            k1_nx[r] = (1.0f - hv * hv) * (p1[r] + p2[r] * SPLIT_INV);
+          }
+          split4(t4, hh[q], hl[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
+      };
+      auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+          *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+        }
+      };
+      auto rotate = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { hr_cu[r] = hr_nx[r]; k1_cu[r] = k1_nx[r]; }
+        C_cu = C_nx; dC_cu = dC_nx; gd_cu = gd_nx;
+      };
+      fetch(split);
+      compute(split + S);
+      rotate();
+      put();
+      __syncthreads();  // A(first)
+      for (int t = split; t < ntiles; t += S) {
+        compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+        __syncthreads();     // B(t)
+        __syncthreads();     // C(t): gW(t) visible
+        // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
+        f32x16 u1 = zero16(), u2 = zero16();
+        {
+          const uint32_t* gp = gwt + c32 * LDA + 8 * h;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(gp + 16 * s);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(gp + 16 * s + 4);
+            u32x4 hi4, lo4;
+            hi4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x05040100u);
+            hi4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x05040100u);
+            hi4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x05040100u);
+            hi4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x05040100u);
+            lo4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x07060302u);
+            lo4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x07060302u);
+            lo4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302u);
+            lo4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x07060302u);
+            f16x8 bh, bl;
+            __builtin_memcpy(&bh, &hi4, 16);
+            __builtin_memcpy(&bl, &lo4, 16);
+            mfma_split(wth[s], wtl[s], bh, bl, u1, u2);
+          }
+        }
+        // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
+        float g_rbf = 0.f, g_c = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float u = u1[r] + u2[r] * SPLIT_INV;
+          g_c += u * hr_cu[r];
+          g_rbf += u * k1_cu[r];
+        }
+        float tot = C_cu * g_rbf + dC_cu * g_c;
+        tot += __shfl_xor(tot, 32, 64);
+        if (h == 0) red[w * 32 + c32] = tot;
+        __syncthreads();     // D(t): gW consumed, partial sums visible
+        if (w == 0 && h == 0) {
+          const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
+          pgd[t * 32 + c32] = FIRST ? sum : gd_cu + sum;
+        }
+        put();               // hidden tiles of t+S
+        rotate();
+        __syncthreads();     // A(t+S)
+      }
+    } else {
+      // ------------------------------------------------------------------ consumer waves
+      f16x8 b1h[8], b1l[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
+        b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+      }
+      const int col = 32 * w + c32;
+      const uint32_t col4 = (uint32_t)col * 4u;
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F);
+      char* gx1b = reinterpret_cast<char*>(gx1);
+      SegRegsB X;
+      uint32_t oj_m[16], oi_m[4];
+      float cr_m[16];
+      auto fetch_meta = [&](int t) {
+        const int base = min(t * 32, last_base);
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+          oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
+          const f32x4 c = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
+          cr_m[4 * q] = c[0]; cr_m[4 * q + 1] = c[1]; cr_m[4 * q + 2] = c[2]; cr_m[4 * q + 3] = c[3];
+          oi_m[q] = poi[base + 8 * q + 4 * h];
+        });
+      };
+      auto fill = [&]() {  // X <- fetched tile: offsets, gathers of x1 and d/d(agg) rows
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+            X.cr[4 * q + e] = cr_m[4 * q + e];
+          }
+        });
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+          X.gi[q] = *reinterpret_cast<const float*>(gab + X.oi[q]);
+        });
+        static_for<0, 16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          X.xj[r] = *reinterpret_cast<const float*>(x1b + X.oj[r]);
+          X.gj[r] = *reinterpret_cast<const float*>(gab + X.oj[r]);
+        });
+      };
+      fetch_meta(split);
+      fill();
+      fetch_meta(split + S);
+      __syncthreads();  // A(first)
+      for (int t = split; t < ntiles; t += S) {
+        // L1 recomputed: filt slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16(), acc2 = zero16();
+        {
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ph + 16 * s);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+            mfma_split(ah, al, b1h[s], b1l[s], acc1, acc2);
+          }
+        }
+        f32x16 fl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fl[r] = acc1[r] + acc2[r] * SPLIT_INV;
+        // gW = x1[i] g[j] + x1[j] g[i], split and packed (hi | lo << 16)
+        uint32_t gwp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float gw = X.xi[r >> 2] * X.gj[r] + X.xj[r] * X.gi[r >> 2];
+          const hv2 h1 = __builtin_amdgcn_cvt_pkrtz(gw, 0.0f);
+          const float rem = (gw - (float)h1[0]) * SPLIT_SCALE;
+          const hv2 pk = __builtin_amdgcn_cvt_pkrtz(gw, rem);
+          __builtin_memcpy(&gwp[r], &pk, 4);
+        }
+        asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
+        __syncthreads();  // B(t): hidden tiles consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gwt[tile_row(r, h) * LDA + col] = gwp[r];
+        __syncthreads();  // C(t): gW visible
+        if (NEED_GX1) {   // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j)
+          static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float Wq[4], vj[4];
+            float si = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              Wq[e] = fl[4 * q + e] * X.cr[4 * q + e];
+              vj[e] = *reinterpret_cast<const float*>(gx1b + X.oj[4 * q + e]);
+              si += X.gj[4 * q + e] * Wq[e];
+            }
+            const float cval = *reinterpret_cast<const float*>(gx1b + X.oi[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              *reinterpret_cast<float*>(gx1b + X.oj[4 * q + e]) = vj[e] + X.gi[q] * Wq[e];
+            si += __shfl_xor(si, 32, 64);
+            *reinterpret_cast<float*>(gx1b + X.oi[q]) = cval + si;
+          });
+        }
+        fill();           // X <- tile t+S
+        fetch_meta(t + 2 * S);
+        __syncthreads();  // D(t)
+        __syncthreads();  // A(t+S)
+      }
+    }
+  }
+  if (NEED_GX1) {
+    __syncthreads();
+    float* out = a.slabs + split * a.slab_stride + a0 * F;
+    for (int i = tid * 4; i < n * F; i += 2048)
+      *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(gx1 + i);
+  }
 }
 
 template <int KS0, bool NEED_GX1, bool FIRST>
@@ -1208,7 +1760,7 @@ bool desc_ok(const fmd_schnet_desc* d) {
   for (int k = 0; k < d->num_out; ++k)
     if (d->out_width[k] < 1 || d->out_width[k] > F) return false;
   if (d->out_width[d->num_out - 1] != 1) return false;
-  if (d->precision != FMD_PREC_F32) return false;
+  if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_F32_MFMA) return false;
   if (d->embedding_size < 1) return false;
   return true;
 }
@@ -1217,19 +1769,32 @@ template <int KS0>
 int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, dim3 grid, size_t lds,
               hipStream_t s) {
   if (fwd) {
-    if (getenv("FMD_FWD_4WAVE")) {
+    const char* mode = getenv("FMD_EDGE_FWD");  // experiments: "4wave" | "ws" | default split
+    if (mode && mode[0] == '4') {
       if (ea.stamps) edge_fwd_kernel<KS0, true><<<grid, 256, lds, s>>>(ea);
       else edge_fwd_kernel<KS0, false><<<grid, 256, lds, s>>>(ea);
-    } else {
+    } else if ((mode && mode[0] == 'w') || d->precision == FMD_PREC_F32_MFMA) {
       if (ea.stamps) edge_fwd_ws_kernel<KS0, true><<<grid, 512, lds, s>>>(ea);
       else edge_fwd_ws_kernel<KS0, false><<<grid, 512, lds, s>>>(ea);
+    } else {
+      constexpr int NS0 = (2 * KS0 + 15) / 16;
+      edge_fwd_split_kernel<NS0><<<grid, 512, lds, s>>>(ea);
     }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
-    if (need && first) edge_bwd_kernel<KS0, true, true><<<grid, 256, lds, s>>>(ea);
-    else if (need) edge_bwd_kernel<KS0, true, false><<<grid, 256, lds, s>>>(ea);
-    else if (first) edge_bwd_kernel<KS0, false, true><<<grid, 256, lds, s>>>(ea);
-    else edge_bwd_kernel<KS0, false, false><<<grid, 256, lds, s>>>(ea);
+    const char* mode = getenv("FMD_EDGE_BWD");  // experiments: "4wave" | default split
+    if ((mode && mode[0] == '4') || d->precision == FMD_PREC_F32_MFMA) {
+      if (need && first) edge_bwd_kernel<KS0, true, true><<<grid, 256, lds, s>>>(ea);
+      else if (need) edge_bwd_kernel<KS0, true, false><<<grid, 256, lds, s>>>(ea);
+      else if (first) edge_bwd_kernel<KS0, false, true><<<grid, 256, lds, s>>>(ea);
+      else edge_bwd_kernel<KS0, false, false><<<grid, 256, lds, s>>>(ea);
+    } else {
+      constexpr int NS0 = (2 * KS0 + 15) / 16;
+      if (need && first) edge_bwd_split_kernel<NS0, true, true><<<grid, 512, lds, s>>>(ea);
+      else if (need) edge_bwd_split_kernel<NS0, true, false><<<grid, 512, lds, s>>>(ea);
+      else if (first) edge_bwd_split_kernel<NS0, false, true><<<grid, 512, lds, s>>>(ea);
+      else edge_bwd_split_kernel<NS0, false, false><<<grid, 512, lds, s>>>(ea);
+    }
   }
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
@@ -1248,6 +1813,9 @@ hipError_t set_edge_attrs(size_t lds) {
   e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1257,7 +1825,20 @@ hipError_t set_edge_attrs(size_t lds) {
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, false, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, false, false>,
+  e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, false, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  constexpr int NS0 = (2 * KS0 + 15) / 16;
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, false>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -1293,6 +1874,9 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     pack_slice(out + o.l3, b.lin_w, F, F, false);
     memcpy(out + o.b3, b.lin_b, F * sizeof(float));
     pack_slice(out + o.l3t, b.lin_w, F, F, true);
+    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false);
+    pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false);
+    pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
   }
   int in_w = F;
   for (int k = 0; k < desc->num_out; ++k) {
@@ -1348,7 +1932,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   FMD_CHECK_LAUNCH();
 
   const int ks0 = (desc->num_rbf + 1) / 2;
-  const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + max_beads_per_mol * F) * sizeof(float);
+  // [tile region 4352 floats][red 128][centres 64][aggregate rows]
+  const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + 128 + 64 + max_beads_per_mol * F) * sizeof(float);
   hipError_t he = ks0 <= 16 ? set_edge_attrs<16>(lds_edge)
                   : ks0 <= 25 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
   if (he != hipSuccess) return FMD_ELAUNCH;
@@ -1364,6 +1949,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.poi = ws.poi; ea.poj = ws.poj; ea.pd = ws.pd; ea.pc = ws.pc; ea.pdc = ws.pdc; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
     ea.mol_ptr = mol_ptr; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
     ea.p0 = pk + o.p0; ea.b0 = pk + o.b0; ea.p1 = pk + o.p1; ea.p1t = pk + o.p1t;
+    ea.q0h = pk + o.q0h; ea.q0l = pk + o.q0l; ea.q1h = pk + o.q1h; ea.q1l = pk + o.q1l;
+    ea.q1th = pk + o.q1th; ea.q1tl = pk + o.q1tl;
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);

@@ -151,10 +151,14 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
  * (models/gradients.py:226-290) for StandardSchNet models (Gaussian basis, cosine cutoff with
  * lower bound 0, tanh, hidden = filters = 128).
  *   Weights are packed once by fmd_schnet_pack_bytes / fmd_schnet_pack (device buffer).
- *   precision: FMD_PREC_F32 (exact fp32 MFMA); FMD_PREC_W16A16 is reserved (returns FMD_EINVAL).
+ *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as
+ *   fp16 hi + lo/2048 and a.b = hi.hi + (hi.lo + lo.hi)/2048 on v_mfma_f32_32x32x16_f16 with fp32
+ *   accumulation -- relative error 2e-7, the same as fp32 MFMA, at 3/16 of its MFMA cycles) or
+ *   FMD_PREC_F32_MFMA (exact fp32 products); FMD_PREC_W16A16 is reserved (returns FMD_EINVAL).
  * ------------------------------------------------------------------------------------------- */
-#define FMD_PREC_F32 0
-#define FMD_PREC_W16A16 1
+#define FMD_PREC_F32 0        /* fp32 results: fp16 hi/lo split operands on the fp16 MFMA, fp32 accumulate */
+#define FMD_PREC_W16A16 1     /* reserved */
+#define FMD_PREC_F32_MFMA 2   /* fp32 results: exact fp32 products on v_mfma_f32_32x32x2_f32 */
 
 typedef struct fmd_schnet_desc {
   int32_t hidden;        /* = num_filters = 128 */
@@ -196,7 +200,7 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
                                    int64_t max_pairs_per_mol);
 /* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY, [1] = max pairs seen in one molecule,
  * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
-/* max_beads_per_mol: upper bound on beads of one molecule (<= 286: the per-molecule aggregate lives
+/* max_beads_per_mol: upper bound on beads of one molecule (<= 284: the per-molecule aggregate lives
  * in LDS; larger molecules return FMD_EUNSUPPORTED and take the operator path).
  * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
  *   multiples of 8 entries; A(A-1)/2 + 8A can never overflow.
