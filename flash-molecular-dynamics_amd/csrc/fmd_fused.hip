@@ -191,46 +191,55 @@ __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict_
 // neighbours j are distinct and the centre is shared, which lets the edge kernels accumulate with
 // plain LDS read-modify-write (no float atomics) and one in-register reduction per segment.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ pos,
+__global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ pos,
                                                     const int64_t* __restrict__ mol_ptr, float rc2,
                                                     float rc, int cap, uint32_t* __restrict__ poi,
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ status) {
+  // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin):
+  // lanes sweep the candidates j > i 64 at a time from LDS, hits are counted / compacted with a ballot.
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x, tid = threadIdx.x;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
   const int n = (int)(mol_ptr[m + 1] - a0);
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
-  int* rowcount = reinterpret_cast<int*>(sz + n);  // [n]
-  __shared__ int wave_tot[4], wave_real[4];
-  for (int i = tid; i < n; i += 256) {
+  int* rowstart = reinterpret_cast<int*>(sz + n);  // [n + 1]: counts, then padded exclusive offsets
+  __shared__ int wave_tot[16], real_tot[16];
+  for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
     sz[i] = pos[3 * (a0 + i) + 2];
   }
   __syncthreads();
-  // rows are dealt in contiguous chunks so one block scan orders them
-  const int per = (n + 255) / 256;
+  auto hit = [&](int i, int j, float& d2) {
+    const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
+    d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    return d2 < rc2;
+  };
+  // ---- pass 1: row counts
+  for (int i = wv; i < n; i += 16) {
+    int c = 0;
+    for (int j0 = i + 1; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      float d2;
+      const bool hh = j < n && hit(i, j, d2);
+      c += __popcll(__ballot(hh));
+    }
+    if (lane == 0) rowstart[i] = c;
+  }
+  __syncthreads();
+  // ---- exclusive scan of the padded counts (contiguous chunk of rows per thread)
+  const int per = (n + 1023) / 1024;
   const int i_lo = min(n, tid * per), i_hi = min(n, i_lo + per);
   int mine = 0, mine_real = 0;
   for (int i = i_lo; i < i_hi; ++i) {
-    const float xi = sx[i], yi = sy[i], zi = sz[i];
-    int c = 0;
-    for (int j = i + 1; j < n; ++j) {
-      const float dx = __fsub_rn(sx[j], xi), dy = __fsub_rn(sy[j], yi), dz = __fsub_rn(sz[j], zi);
-      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      c += d2 < rc2 ? 1 : 0;
-    }
-    rowcount[i] = c;
-    mine += (c + 7) & ~7;
-    mine_real += c;
+    mine += (rowstart[i] + 7) & ~7;
+    mine_real += rowstart[i];
   }
-  // exclusive scan of per-thread padded totals
-  const int lane = tid & 63, wv = tid >> 6;
   int incl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -241,53 +250,62 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) real_w += __shfl_xor(real_w, o, 64);
   if (lane == 63) wave_tot[wv] = incl;
-  if (lane == 0) wave_real[wv] = real_w;
+  if (lane == 0) real_tot[wv] = real_w;
   __syncthreads();
   int base = incl - mine;
   for (int q = 0; q < wv; ++q) base += wave_tot[q];
-  const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  int total = 0;
+  for (int q = 0; q < 16; ++q) total += wave_tot[q];
+  __syncthreads();  // every thread has read the counts it needs before they are overwritten
+  for (int i = i_lo; i < i_hi; ++i) {
+    const int c = rowstart[i];
+    rowstart[i] = base;  // padded offset of the row (pass 2 recounts while filling)
+    base += (c + 7) & ~7;
+  }
+  __syncthreads();
+  // ---- pass 2: fill (ballot-compacted, sorted by j), cutoff values computed once per pair here
   uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
   uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
   float* d_out = pd + (int64_t)m * cap;
   float* c_out = pc + (int64_t)m * cap;
   float* dc_out = pdc + (int64_t)m * cap;
-  for (int i = i_lo; i < i_hi; ++i) {
-    const float xi = sx[i], yi = sy[i], zi = sz[i];
-    int k = base;
-    const int kend = base + ((rowcount[i] + 7) & ~7);
-    base = kend;
-    for (int j = i + 1; j < n; ++j) {
-      const float dx = __fsub_rn(sx[j], xi), dy = __fsub_rn(sy[j], yi), dz = __fsub_rn(sz[j], zi);
-      const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      if (d2 < rc2) {
-        if (k < cap) {
-          oi_out[k] = (uint32_t)i * (F * 4);
-          oj_out[k] = (uint32_t)j * (F * 4);
+  for (int i = wv; i < n; i += 16) {
+    int k = rowstart[i];
+    for (int j0 = i + 1; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      float d2 = 0.f;
+      const bool hh = j < n && hit(i, j, d2);
+      const unsigned long long mk = __ballot(hh);
+      if (hh) {
+        const int kk = k + __popcll(mk & ((1ull << lane) - 1ull));
+        if (kk < cap) {
           const float d = sqrtf(d2);
           float C, dC;
-          fmd_cutoff2(d, rc, C, dC);  // cosine cutoff and derivative, once per pair per timestep
-          d_out[k] = d;
-          c_out[k] = C;
-          dc_out[k] = dC;
+          fmd_cutoff2(d, rc, C, dC);
+          oi_out[kk] = (uint32_t)i * (F * 4);
+          oj_out[kk] = (uint32_t)j * (F * 4);
+          d_out[kk] = d;
+          c_out[kk] = C;
+          dc_out[kk] = dC;
         }
-        ++k;
       }
+      k += __popcll(mk);
     }
-    for (; k < kend; ++k)
-      if (k < cap) {
-        oi_out[k] = (uint32_t)i * (F * 4);
-        oj_out[k] = (uint32_t)i * (F * 4);
-        d_out[k] = rc;
-        c_out[k] = 0.f;
-        dc_out[k] = 0.f;
-      }
+    const int kend = (k + 7) & ~7;  // pad the centre's run to a multiple of 8 with (i, i), C = 0
+    if (k + lane < kend && k + lane < cap) {
+      oi_out[k + lane] = (uint32_t)i * (F * 4);
+      oj_out[k + lane] = (uint32_t)i * (F * 4);
+      d_out[k + lane] = rc;
+      c_out[k + lane] = 0.f;
+      dc_out[k + lane] = 0.f;
+    }
   }
   // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
   // need a validity test
   {
     const int tot_c = min(total, cap) & ~7;
     const int tot32 = min((tot_c + 31) & ~31, cap);
-    for (int k = tot_c + tid; k < tot32; k += 256) {
+    for (int k = tot_c + tid; k < tot32; k += 1024) {
       oi_out[k] = 0u;
       oj_out[k] = 0u;
       d_out[k] = rc;
@@ -296,7 +314,8 @@ __global__ __launch_bounds__(256) void pairs_kernel(const float* __restrict__ po
     }
   }
   if (tid == 0) {
-    const int real = wave_real[0] + wave_real[1] + wave_real[2] + wave_real[3];
+    int real = 0;
+    for (int q = 0; q < 16; ++q) real += real_tot[q];
     npairs[m] = min(total, cap) & ~7;
     if (total > cap) status[0] = FMD_ECAPACITY;
     atomicMax(&status[1], total);
@@ -1651,47 +1670,73 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
   }
 }
 
-// one wave per molecule: forces from dE/dd of its pairs, energy from its beads (fixed order)
-__global__ __launch_bounds__(64) void finish_kernel(const float* __restrict__ pos,
-                                                    const int64_t* __restrict__ mol_ptr,
-                                                    const uint32_t* __restrict__ poi,
-                                                    const uint32_t* __restrict__ poj,
-                                                    const float* __restrict__ pd,
-                                                    const float* __restrict__ pgd,
-                                                    const int32_t* __restrict__ npairs, int cap,
-                                                    const float* __restrict__ e_node,
-                                                    float* __restrict__ energy,
-                                                    float* __restrict__ forces) {
+// one workgroup (4 waves) per molecule: forces from dE/dd of its pairs, energy from its beads.
+// Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered inside one
+// wave); the four copies are added in fixed order, so the result is reproducible.
+__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
+                                                     const int64_t* __restrict__ mol_ptr,
+                                                     const uint32_t* __restrict__ poi,
+                                                     const uint32_t* __restrict__ poj,
+                                                     const float* __restrict__ pd,
+                                                     const float* __restrict__ pgd,
+                                                     const int32_t* __restrict__ npairs, int cap,
+                                                     const float* __restrict__ e_node,
+                                                     float* __restrict__ energy,
+                                                     float* __restrict__ forces) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x, lane = threadIdx.x;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
   const int n = (int)(mol_ptr[m + 1] - a0);
-  float* g = smem;  // [3n] dE/dpos
-  for (int i = lane; i < 3 * n; i += 64) g[i] = 0.f;
+  float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos
+  __shared__ float esum[4];
+  for (int i = tid; i < 12 * n; i += 256) smem[i] = 0.f;
+  __syncthreads();
   const int np = npairs[m];
-  for (int p0 = 0; p0 < np; p0 += 64) {
-    const int p = p0 + lane;
-    if (p < np) {
-      const int i = (int)(poi[(int64_t)m * cap + p] / (F * 4));
-      const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
+  // every thread walks a contiguous run of the (centre-sorted) list: the centre's contribution is
+  // summed in registers and flushed when the centre changes, so lanes rarely collide in LDS
+  const int chunk = (np + 255) / 256;
+  const int p_lo = min(np, tid * chunk), p_hi = min(np, p_lo + chunk);
+  int ci = -1;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int p = p_lo; p < p_hi; ++p) {
+    const int i = (int)(poi[(int64_t)m * cap + p] / (F * 4));
+    const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
+    if (i != ci) {
+      if (ci >= 0) {
+        atomicAdd(&g[3 * ci], cx);
+        atomicAdd(&g[3 * ci + 1], cy);
+        atomicAdd(&g[3 * ci + 2], cz);
+      }
+      ci = i;
+      cx = cy = cz = 0.f;
+    }
+    if (i != j) {  // pad entries carry nothing
       const float d = fmaxf(pd[(int64_t)m * cap + p], 1e-8f);
       const float s = pgd[(int64_t)m * cap + p] / d;
-      const float dx = pos[3 * (a0 + j)] - pos[3 * (a0 + i)];
-      const float dy = pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1];
-      const float dz = pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2];
-      atomicAdd(&g[3 * j], s * dx);
-      atomicAdd(&g[3 * j + 1], s * dy);
-      atomicAdd(&g[3 * j + 2], s * dz);
-      atomicAdd(&g[3 * i], -s * dx);
-      atomicAdd(&g[3 * i + 1], -s * dy);
-      atomicAdd(&g[3 * i + 2], -s * dz);
+      const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
+      const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
+      const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
+      atomicAdd(&g[3 * j], dx);
+      atomicAdd(&g[3 * j + 1], dy);
+      atomicAdd(&g[3 * j + 2], dz);
+      cx -= dx;
+      cy -= dy;
+      cz -= dz;
     }
   }
-  for (int i = lane; i < 3 * n; i += 64) forces[3 * a0 + i] = -g[i];
+  if (ci >= 0) {
+    atomicAdd(&g[3 * ci], cx);
+    atomicAdd(&g[3 * ci + 1], cy);
+    atomicAdd(&g[3 * ci + 2], cz);
+  }
   float e = 0.f;
-  for (int i = lane; i < n; i += 64) e += e_node[a0 + i];
+  for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
   e = fmd_wave_sum(e);
-  if (lane == 0) energy[m] = e;
+  if (lane == 0) esum[wv] = e;
+  __syncthreads();
+  for (int i = tid; i < 3 * n; i += 256)
+    forces[3 * a0 + i] = -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]);
+  if (tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
 }
 
 void* g_stamp_buffer = nullptr;  // set by fmd_debug_set_stamp_buffer (diagnostics, never in timed runs)
@@ -1925,7 +1970,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
   const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
   ev_begin();
-  pairs_kernel<<<(unsigned)n_mol, 256, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
+  pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
                                                      ws.pc, ws.pdc, ws.npairs, status);
   ev_end();
@@ -2021,7 +2066,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     if (rc != FMD_OK) return rc;
   }
   ev_begin();
-  finish_kernel<<<(unsigned)n_mol, 64, 3 * max_beads_per_mol * sizeof(float), s>>>(
+  finish_kernel<<<(unsigned)n_mol, 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
       pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, ws.npairs, (int)cap, ws.e_node, energy, forces);
   ev_end();
   FMD_CHECK_LAUNCH();
