@@ -113,6 +113,12 @@ void pack_split(float* dst_hi, float* dst_lo, const float* M, int n_out, int n_k
           lo[idx] = (_Float16)((v - (float)h) * 2048.0f);
         }
 }
+// node-kernel operand: fp32 slice, or (same footprint: SLICE == 2 * Q1_FLOATS) its hi/lo fp16 split
+void pack_node(float* dst, const float* M, int n_out, int n_k, bool transposed, bool split) {
+  static_assert(SLICE == 2 * Q1_FLOATS, "split records must fit the fp32 slice");
+  if (split) pack_split(dst, dst + Q1_FLOATS, M, n_out, n_k, 8, transposed);
+  else pack_slice(dst, M, n_out, n_k, transposed);
+}
 // filter layer 0 as the A operand of hidden^T = W0 rbf^T: lane l, step s: f0_w[32w+(l&31)][2s+(l>>5)]
 void pack_p0(float* dst, const float* f0_w, int n_rbf) {
   for (int w = 0; w < 4; ++w)
@@ -134,6 +140,55 @@ __device__ __forceinline__ f32x16 zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time unrolled loop: the body receives std::integral_constant<int, I> (true constants keep
+// every register-array index static, so nothing is demoted to scratch)
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int LDH = 136;                       // halves per row of an fp16 LDS tile (272 B)
+constexpr int TILE_H_BYTES = 32 * LDH * 2;     // one fp16 tile
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+
+// 8 fp32 values -> hi / lo fp16 fragments
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
+    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
+    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
+    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
+    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
+  }
+}
+__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
+    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
+    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
+    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
+    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
+  }
+}
+// acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
+__device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
+                                           const f16x8& bl, f32x16& acc1, f32x16& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+}
+
 
 // rows x 128 tile in LDS (stride LDA) times a packed operand streamed from global/L2:
 // result lane = output column 32w + (lane&31), register r = tile row tile_row(r, lane>>5)
@@ -166,7 +221,80 @@ __device__ __forceinline__ void tile_to_lds(float* buf, const f32x16& v, int w, 
   for (int r = 0; r < 16; ++r) buf[tile_row(r, h) * LDA + col] = v[r];
 }
 
+// ---- split-operand forms of the node helpers (precision FMD_PREC_F32): the LDS tile holds
+// u32 = f16 hi | f16 lo << 16 per element, the operand record is [hi 8 steps][lo 8 steps] of 16-byte
+// fragments (pack_split), a 128-deep slice costs 24 fp16 MFMAs instead of 64 fp32 ones.
+__device__ __forceinline__ uint32_t pack_hl(float v) {
+  const hv2 h1 = __builtin_amdgcn_cvt_pkrtz(v, 0.0f);
+  const hv2 pk = __builtin_amdgcn_cvt_pkrtz(v, (v - (float)h1[0]) * SPLIT_SCALE);
+  uint32_t u;
+  __builtin_memcpy(&u, &pk, 4);
+  return u;
+}
+// 8 consecutive packed elements -> hi / lo fragments
+__device__ __forceinline__ void unpack_frag(const u32x4& v0, const u32x4& v1, f16x8& hi, f16x8& lo) {
+  u32x4 hi4, lo4;
+  hi4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x05040100u);
+  hi4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x05040100u);
+  hi4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x05040100u);
+  hi4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x05040100u);
+  lo4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x07060302u);
+  lo4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x07060302u);
+  lo4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302u);
+  lo4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x07060302u);
+  __builtin_memcpy(&hi, &hi4, 16);
+  __builtin_memcpy(&lo, &lo4, 16);
+}
+__device__ __forceinline__ f32x16 gemm_rows_split(const float* lds_a, const float* __restrict__ pk,
+                                                  int w, int lane) {
+  f32x16 acc1 = zero16(), acc2 = zero16();
+  const uint32_t* ap = reinterpret_cast<const uint32_t*>(lds_a) + (lane & 31) * LDA + 8 * (lane >> 5);
+  const f16x8* bh = reinterpret_cast<const f16x8*>(pk) + (int64_t)w * 8 * 64 + lane;
+  const f16x8* bl = reinterpret_cast<const f16x8*>(pk + Q1_FLOATS) + (int64_t)w * 8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(ap + 16 * s);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(ap + 16 * s + 4);
+    f16x8 ah, al;
+    unpack_frag(v0, v1, ah, al);
+    mfma_split(ah, al, bh[s * 64], bl[s * 64], acc1, acc2);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] += acc2[r] * SPLIT_INV;
+  return acc1;
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x16 gemm_rows(const float* lds_a, const float* __restrict__ pk, int w,
+                                            int lane) {
+  if (SPLIT) return gemm_rows_split(lds_a, pk, w, lane);
+  return gemm_rows_packed(lds_a, pk, w, lane);
+}
+template <bool SPLIT>
+__device__ __forceinline__ f32x16 gemm_rows_nohoist(const float* lds_a, const float* pk, int w, int lane) {
+  asm volatile("" : "+s"(pk));
+  return gemm_rows<SPLIT>(lds_a, pk, w, lane);
+}
+template <bool SPLIT>
+__device__ __forceinline__ void tile_store(float* buf, const f32x16& v, int w, int lane) {
+  const int col = 32 * w + (lane & 31), h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (SPLIT) reinterpret_cast<uint32_t*>(buf)[tile_row(r, h) * LDA + col] = pack_hl(v[r]);
+    else buf[tile_row(r, h) * LDA + col] = v[r];
+  }
+}
+template <bool SPLIT>
+__device__ __forceinline__ void tile_store4(float* buf, int r, int c, const f32x4& v) {
+  if (SPLIT) {
+    const u32x4 u = {pack_hl(v[0]), pack_hl(v[1]), pack_hl(v[2]), pack_hl(v[3])};
+    *reinterpret_cast<u32x4*>(reinterpret_cast<uint32_t*>(buf) + r * LDA + c) = u;
+  } else {
+    *reinterpret_cast<f32x4*>(buf + r * LDA + c) = v;
+  }
+}
+
 // 32 rows x 128 floats global -> LDS tile (rows beyond n_rows zero-filled), optional sum of slabs
+template <bool SPLIT>
 __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict__ src,
                                             int64_t slab_stride, int n_slabs, int64_t row0,
                                             int64_t n_rows, int tid) {
@@ -180,7 +308,7 @@ __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict_
       v = *reinterpret_cast<const f32x4*>(p);
       for (int s = 1; s < n_slabs; ++s) v += *reinterpret_cast<const f32x4*>(p + s * slab_stride);
     }
-    *reinterpret_cast<f32x4*>(buf + r * LDA + c) = v;
+    tile_store4<SPLIT>(buf, r, c, v);
   }
 }
 
@@ -349,18 +477,6 @@ struct EdgeArgs {
   int cap, n_split;
   unsigned long long* stamps;  // diagnostic builds only
 };
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// compile-time unrolled loop: the body receives std::integral_constant<int, I> (true constants keep
-// every register-array index static, so nothing is demoted to scratch)
-template <int I, int N, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 template <int KS0, bool STAMP>
 __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
@@ -750,42 +866,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
 // fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
 // edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
 // =================================================================================================
-constexpr int LDH = 136;                       // halves per row of an fp16 LDS tile (272 B)
-constexpr int TILE_H_BYTES = 32 * LDH * 2;     // one fp16 tile
-constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
-typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
-
-// 8 fp32 values -> hi / lo fp16 fragments
-__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
-    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
-    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
-    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
-    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
-  }
-}
-__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[2 * j], x[2 * j + 1]);
-    const float r0 = (x[2 * j] - (float)h[0]) * SPLIT_SCALE;
-    const float r1 = (x[2 * j + 1] - (float)h[1]) * SPLIT_SCALE;
-    const hv2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    hi[2 * j] = (_Float16)h[0]; hi[2 * j + 1] = (_Float16)h[1];
-    lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
-  }
-}
-// acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
-__device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
-                                           const f16x8& bl, f32x16& acc1, f32x16& acc2) {
-  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
-  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
-  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
-}
-
 template <int NS0>  // k-steps of 16 covering the rbf index (ceil(R / 16))
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1456,7 +1536,7 @@ struct NodeFwdArgs {
   int64_t n_nodes;
 };
 
-template <bool FIRST>
+template <bool FIRST, bool SPLIT>
 __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
@@ -1477,12 +1557,12 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
           v = *reinterpret_cast<const f32x4*>(a.emb + ty * F + c);
           *reinterpret_cast<f32x4*>(a.x + (row0 + r) * F + c) = v;
         }
-        *reinterpret_cast<f32x4*>(bufA + r * LDA + c) = v;
+        tile_store4<SPLIT>(bufA, r, c, v);
       }
     } else {
-      rows_to_lds(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
+      rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
       __syncthreads();
-      f32x16 acc = gemm_rows_packed(bufA, a.l2, w, lane);  // conv = agg lin2^T + b2
+      f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);  // conv = agg lin2^T + b2
       const float b2 = a.b2[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1490,9 +1570,9 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
         const int64_t row = row0 + tile_row(r, h);
         if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
       }
-      tile_to_lds(bufB, acc, w, lane);
+      tile_store<SPLIT>(bufB, acc, w, lane);
       __syncthreads();
-      acc = gemm_rows_packed(bufB, a.l3, w, lane);  // y = tanh(conv) lin^T + b3 ; x += y
+      acc = gemm_rows<SPLIT>(bufB, a.l3, w, lane);  // y = tanh(conv) lin^T + b3 ; x += y
       const float b3 = a.b3[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1504,10 +1584,10 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
         }
         acc[r] = xn;
       }
-      tile_to_lds(bufA, acc, w, lane);
+      tile_store<SPLIT>(bufA, acc, w, lane);
     }
     __syncthreads();
-    const f32x16 x1 = gemm_rows_packed(bufA, a.l1, w, lane);  // x1 = x lin1^T
+    const f32x16 x1 = gemm_rows<SPLIT>(bufA, a.l1, w, lane);  // x1 = x lin1^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
@@ -1532,7 +1612,7 @@ struct NodeOutArgs {
   int64_t n_nodes;
 };
 
-template <int NUM_OUT>
+template <int NUM_OUT, bool SPLIT>
 __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
@@ -1541,9 +1621,9 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32;
-    rows_to_lds(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
+    rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
     __syncthreads();
-    f32x16 acc = gemm_rows_packed(bufA, a.l2, w, lane);
+    f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);
     const float b2 = a.b2[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1551,16 +1631,16 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
       const int64_t row = row0 + tile_row(r, h);
       if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
     }
-    tile_to_lds(bufB, acc, w, lane);
+    tile_store<SPLIT>(bufB, acc, w, lane);
     __syncthreads();
-    acc = gemm_rows_packed(bufB, a.l3, w, lane);
+    acc = gemm_rows<SPLIT>(bufB, a.l3, w, lane);
     const float b3 = a.b3[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
       acc[r] = row < a.n_nodes ? a.x[row * F + col] + (acc[r] + b3) : 0.f;
     }
-    tile_to_lds(bufA, acc, w, lane);
+    tile_store<SPLIT>(bufA, acc, w, lane);
     __syncthreads();
     // ---- output network forward (tanh hidden layers, last layer linear without bias)
     f32x16 hk[2];
@@ -1568,15 +1648,15 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     float* nxt = bufB;
 #pragma unroll
     for (int k = 0; k < NUM_OUT - 1; ++k) {
-      hk[k] = gemm_rows_streamed(cur, a.po[k], w, lane);
+      hk[k] = gemm_rows_nohoist<SPLIT>(cur, a.po[k], w, lane);
       const float bk = a.bo[k][col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh_fast(hk[k][r] + bk);
-      tile_to_lds(nxt, hk[k], w, lane);
+      tile_store<SPLIT>(nxt, hk[k], w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    const f32x16 e = gemm_rows_streamed(cur, a.po[NUM_OUT - 1], w, lane);
+    const f32x16 e = gemm_rows_nohoist<SPLIT>(cur, a.po[NUM_OUT - 1], w, lane);
     if (col == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1588,19 +1668,19 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = col == 0 ? 1.0f : 0.0f;
-    tile_to_lds(nxt, g, w, lane);
+    tile_store<SPLIT>(nxt, g, w, lane);
     __syncthreads();
     { float* tmp = cur; cur = nxt; nxt = tmp; }
 #pragma unroll
     for (int k = NUM_OUT - 1; k >= 1; --k) {
-      g = gemm_rows_streamed(cur, a.pot[k], w, lane);
+      g = gemm_rows_nohoist<SPLIT>(cur, a.pot[k], w, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
-      tile_to_lds(nxt, g, w, lane);
+      tile_store<SPLIT>(nxt, g, w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    g = gemm_rows_streamed(cur, a.pot[0], w, lane);
+    g = gemm_rows_nohoist<SPLIT>(cur, a.pot[0], w, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
@@ -1622,7 +1702,7 @@ struct NodeBwdArgs {
   int64_t n_nodes;
 };
 
-template <bool HAS_SLABS>
+template <bool HAS_SLABS, bool SPLIT>
 __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
@@ -1633,9 +1713,9 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
     const int64_t row0 = tile * 32;
     f32x16 acc;
     if (HAS_SLABS) {  // gx += (sum of gx1 partials) lin1
-      rows_to_lds(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
+      rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
       __syncthreads();
-      acc = gemm_rows_packed(bufA, a.l1t, w, lane);
+      acc = gemm_rows<SPLIT>(bufA, a.l1t, w, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + tile_row(r, h);
@@ -1646,21 +1726,21 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
         }
         acc[r] = v;
       }
-      tile_to_lds(bufB, acc, w, lane);
+      tile_store<SPLIT>(bufB, acc, w, lane);
     } else {
-      rows_to_lds(bufB, a.gx, 0, 1, row0, a.n_nodes, tid);
+      rows_to_lds<SPLIT>(bufB, a.gx, 0, 1, row0, a.n_nodes, tid);
     }
     __syncthreads();
-    acc = gemm_rows_packed(bufB, a.l3t, w, lane);  // d/d tanh(conv) = gx lin
+    acc = gemm_rows<SPLIT>(bufB, a.l3t, w, lane);  // d/d tanh(conv) = gx lin
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
       const float tv = row < a.n_nodes ? a.t[row * F + col] : 0.f;
       acc[r] *= 1.0f - tv * tv;
     }
-    tile_to_lds(bufA, acc, w, lane);
+    tile_store<SPLIT>(bufA, acc, w, lane);
     __syncthreads();
-    acc = gemm_rows_packed(bufA, a.l2t, w, lane);  // d/d agg = gconv lin2
+    acc = gemm_rows<SPLIT>(bufA, a.l2t, w, lane);  // d/d agg = gconv lin2
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
@@ -1899,6 +1979,7 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
   if (!desc_ok(desc) || !wt || !centers || !packed_host || !wt->embedding || !wt->blocks) return FMD_EINVAL;
   const PackLayout L = pack_layout(desc);
   float* out = reinterpret_cast<float*>(packed_host);
+  const bool split = desc->precision == FMD_PREC_F32;  // node operands in split (hi/lo fp16) form
   memset(out, 0, L.total * sizeof(float));
   memcpy(out + L.emb, wt->embedding, (size_t)desc->embedding_size * F * sizeof(float));
   for (int k = 0; k < desc->num_rbf; ++k) out[L.centers + k] = centers[k];
@@ -1911,14 +1992,14 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     memcpy(out + o.b0, b.f0_b, F * sizeof(float));
     pack_slice(out + o.p1, b.f1_w, F, F, false);
     pack_slice(out + o.p1t, b.f1_w, F, F, true);
-    pack_slice(out + o.l1, b.lin1_w, F, F, false);
-    pack_slice(out + o.l1t, b.lin1_w, F, F, true);
-    pack_slice(out + o.l2, b.lin2_w, F, F, false);
+    pack_node(out + o.l1, b.lin1_w, F, F, false, split);
+    pack_node(out + o.l1t, b.lin1_w, F, F, true, split);
+    pack_node(out + o.l2, b.lin2_w, F, F, false, split);
     memcpy(out + o.b2, b.lin2_b, F * sizeof(float));
-    pack_slice(out + o.l2t, b.lin2_w, F, F, true);
-    pack_slice(out + o.l3, b.lin_w, F, F, false);
+    pack_node(out + o.l2t, b.lin2_w, F, F, true, split);
+    pack_node(out + o.l3, b.lin_w, F, F, false, split);
     memcpy(out + o.b3, b.lin_b, F * sizeof(float));
-    pack_slice(out + o.l3t, b.lin_w, F, F, true);
+    pack_node(out + o.l3t, b.lin_w, F, F, true, split);
     pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false);
     pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false);
     pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
@@ -1928,9 +2009,9 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     if (!wt->out_w[k]) return FMD_EINVAL;
     float* base = out + L.outs + k * L.out_stride;
     const int ow = desc->out_width[k];
-    pack_slice(base, wt->out_w[k], ow, in_w, false);
+    pack_node(base, wt->out_w[k], ow, in_w, false, split);
     if (wt->out_b[k]) memcpy(base + SLICE, wt->out_b[k], ow * sizeof(float));
-    pack_slice(base + SLICE + F, wt->out_w[k], in_w, ow, true);  // (W^T)[o=in][k=out] = W[out][in]
+    pack_node(base + SLICE + F, wt->out_w[k], in_w, ow, true, split);  // (W^T)[o=in][k=out] = W[out][in]
     in_w = ow;
   }
   return FMD_OK;
@@ -1983,8 +2064,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
                   : ks0 <= 25 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
   if (he != hipSuccess) return FMD_ELAUNCH;
 
+  const bool sp = desc->precision == FMD_PREC_F32;
   const int64_t n_tiles = (n_nodes + 31) / 32;
-  const unsigned node_grid = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
+  const unsigned node_grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
   const int64_t slab_stride = n_nodes * F;
   dim3 egrid((unsigned)split, (unsigned)n_mol);
 
@@ -2014,11 +2096,13 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     na.l2 = na.b2 = na.l3 = na.b3 = nullptr; na.t_out = nullptr;
     ev_begin();
     if (l == 0) {
-      node_fwd_kernel<true><<<node_grid, 256, 0, s>>>(na);
+      if (sp) node_fwd_kernel<true, true><<<node_grid, 256, 0, s>>>(na);
+      else node_fwd_kernel<true, false><<<node_grid, 256, 0, s>>>(na);
     } else {
       const BlockOff q = block_off(PL, l - 1);
       na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
-      node_fwd_kernel<false><<<node_grid, 256, 0, s>>>(na);
+      if (sp) node_fwd_kernel<false, true><<<node_grid, 256, 0, s>>>(na);
+      else node_fwd_kernel<false, false><<<node_grid, 256, 0, s>>>(na);
     }
     ev_end();
     FMD_CHECK_LAUNCH();
@@ -2039,8 +2123,13 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     }
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
     ev_begin();
-    if (desc->num_out == 3) node_out_kernel<3><<<node_grid, 256, 0, s>>>(oa);
-    else node_out_kernel<2><<<node_grid, 256, 0, s>>>(oa);
+    if (desc->num_out == 3) {
+      if (sp) node_out_kernel<3, true><<<node_grid, 256, 0, s>>>(oa);
+      else node_out_kernel<3, false><<<node_grid, 256, 0, s>>>(oa);
+    } else {
+      if (sp) node_out_kernel<2, true><<<node_grid, 256, 0, s>>>(oa);
+      else node_out_kernel<2, false><<<node_grid, 256, 0, s>>>(oa);
+    }
     ev_end();
     FMD_CHECK_LAUNCH();
   }
@@ -2053,10 +2142,12 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ba.l1t = nullptr;
     ev_begin();
     if (l == L - 1) {
-      node_bwd_kernel<false><<<node_grid, 256, 0, s>>>(ba);
+      if (sp) node_bwd_kernel<false, true><<<node_grid, 256, 0, s>>>(ba);
+      else node_bwd_kernel<false, false><<<node_grid, 256, 0, s>>>(ba);
     } else {
       ba.l1t = pk + block_off(PL, l + 1).l1t;
-      node_bwd_kernel<true><<<node_grid, 256, 0, s>>>(ba);
+      if (sp) node_bwd_kernel<true, true><<<node_grid, 256, 0, s>>>(ba);
+      else node_bwd_kernel<true, false><<<node_grid, 256, 0, s>>>(ba);
     }
     ev_end();
     FMD_CHECK_LAUNCH();
