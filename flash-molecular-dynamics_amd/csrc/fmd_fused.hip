@@ -866,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
 // fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
 // edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
 // =================================================================================================
-template <int NS0>  // k-steps of 16 covering the rbf index (ceil(R / 16))
+template <int NS0, bool STAMP>  // NS0: k-steps of 16 covering the rbf index (ceil(R / 16))
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -887,7 +887,15 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int ntiles = (np + 31) >> 5;
   const int S = a.n_split;
   const int last_base = (ntiles - 1) * 32;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tprev = 0;  // diagnostic build only
+#define FMD_STAMP(acc)                                         \
+  if (STAMP) {                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc += now_ - tprev;                                       \
+    tprev = now_;                                              \
+  }
   __syncthreads();
+  if (STAMP) tprev = __builtin_readcyclecounter();
   if (split < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
@@ -946,9 +954,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       __syncthreads();  // A(first)
       for (int t = split; t < ntiles; t += S) {
         compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        FMD_STAMP(ts0)
         __syncthreads();     // B(t)
+        FMD_STAMP(ts1)
         put();
+        FMD_STAMP(ts2)
         __syncthreads();     // A(t+S)
+        FMD_STAMP(ts3)
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
@@ -1015,9 +1027,12 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + si;
         });
       };
+      // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
+      // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
+      // between the two barriers where the producers only write LDS.
       fetch_meta(split);
-      fill();
-      fetch_meta(split + S);
+      fill();            // X <- first tile (valid rows for the first, zero-weight, update)
+      f32x16 fl_prev = zero16();
       __syncthreads();  // A(first)
       for (int t = split; t < ntiles; t += S) {
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
@@ -1032,18 +1047,27 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             mfma_split(ah, al, b1h[s], b1l[s], acc1, acc2);
           }
         }
-        f32x16 fl;
+        FMD_STAMP(ts0)
+        message(fl_prev);  // tile t-S (X holds its gathers)
+        fill();            // X <- tile t (meta fetched one tile ago; lands before the next update)
+        fetch_meta(t + S);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fl[r] = acc1[r] + acc2[r] * SPLIT_INV;
-        asm volatile("" : "+v"(fl));  // L1 complete (its LDS reads with it) before the barrier
+        for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r] + acc2[r] * SPLIT_INV;
+        asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
+        FMD_STAMP(ts2)
         __syncthreads();  // B(t): hidden tiles consumed
-        message(fl);      // tile t (X holds its gathers)
-        fill();           // X <- tile t+S (meta fetched one tile ago)
-        fetch_meta(t + 2 * S);
+        FMD_STAMP(ts1)
         __syncthreads();  // A(t+S)
+        FMD_STAMP(ts3)
       }
+      message(fl_prev);  // last tile
     }
   }
+  if (STAMP && lane == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 8 + (producer ? 4 : 0);
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+  }
+#undef FMD_STAMP
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
   for (int i = tid * 4; i < n * F; i += 2048)
@@ -1903,7 +1927,8 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       else edge_fwd_ws_kernel<KS0, false><<<grid, 512, lds, s>>>(ea);
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
-      edge_fwd_split_kernel<NS0><<<grid, 512, lds, s>>>(ea);
+      if (ea.stamps) edge_fwd_split_kernel<NS0, true><<<grid, 512, lds, s>>>(ea);
+      else edge_fwd_split_kernel<NS0, false><<<grid, 512, lds, s>>>(ea);
     }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
@@ -1938,7 +1963,10 @@ hipError_t set_edge_attrs(size_t lds) {
   e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16>,
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,

@@ -15,7 +15,7 @@ eng.energy_forces(pos, types, ptr, 269)
 torch.cuda.synchronize()
 _ffi.lib().fmd_debug_set_stamp_buffer(None)
 b = buf.view(256,4,8).double().cpu()
-names=['region(L1+side)','barrierB','barrierA','-','-','-','-','-'] if not os.environ.get('FMD_FWD_4WAVE') else ['tanh+write','barrierA','L1','message','barrierB','gather-issue','L0','-']
+names=['C: L1','C: wait B','C: message+fill+fetch','C: wait A','P: compute','P: wait B','P: put','P: wait A'] if not os.environ.get('FMD_FWD_4WAVE') else ['tanh+write','barrierA','L1','message','barrierB','gather-issue','L0','-']
 tot = b.sum(-1).mean()
 print('mean cycles per wave', tot.item(), 'tiles ~130 -> per tile', tot.item()/130)
 for k,nm in enumerate(names): print(f'{nm:10s} {b[...,k].mean().item()/130:10.0f} cycles/tile   {100*b[...,k].mean().item()/tot.item():5.1f}%   (wave0 {b[:,0,k].mean().item()/130:.0f}, wave3 {b[:,3,k].mean().item()/130:.0f})')
