@@ -26,7 +26,7 @@ namespace {
 constexpr int F = 128;            // hidden = filters
 constexpr int LDA = 132;          // LDS row stride (floats) of a 32 x 128 operand tile
 constexpr int TILE_FLOATS = 32 * LDA;
-constexpr int MAX_LDS_ROWS = 284; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
+constexpr int MAX_LDS_ROWS = 283; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
 constexpr int SLICE = 4 * 64 * 64;  // floats of one packed 128x128 operand ([wave][k-step][lane])
 constexpr int P0_FLOATS = 4 * 32 * 64;
 
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float diff = d - cen[8 * s + j];
-            x[j] = __expf(a.gamma * diff * diff) * C;
+            x[j] = __expf(a.gamma * diff * diff);  // C is a per-pair (per-lane) scalar: applied to the sums
           }
           f16x8 bh, bl;
           split8(x, bh, bl);
@@ -935,7 +935,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           float t4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            t4[e] = fmd_tanh_fast(acc1[4 * q + e] + acc2[4 * q + e] * SPLIT_INV + b0r[4 * q + e]);
+            // z = C (W0 raw) + b0 ; the tile carries C tanh(z): the consumers' L1 then yields W = filt C
+            t4[e] = C * fmd_tanh_fast(C * (acc1[4 * q + e] + acc2[4 * q + e] * SPLIT_INV) + b0r[4 * q + e]);
           split4(t4, hh[q], hl[q]);
         }
         // pin the computation in front of the barrier that follows
@@ -975,15 +976,12 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       char* aggb = reinterpret_cast<char*>(agg);
       SegRegs X;
       uint32_t oj_m[16], oi_m[4];
-      float cr_m[16];
       auto fetch_meta = [&](int t) {
         const int base = min(t * 32, last_base);
         static_for<0, 4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
           oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
-          const f32x4 c = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
-          cr_m[4 * q] = c[0]; cr_m[4 * q + 1] = c[1]; cr_m[4 * q + 2] = c[2]; cr_m[4 * q + 3] = c[3];
           oi_m[q] = poi[base + 8 * q + 4 * h];
         });
       };
@@ -994,7 +992,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
-            X.cr[4 * q + e] = cr_m[4 * q + e];
           }
         });
         static_for<0, 4>([&](auto qc) {
@@ -1014,7 +1011,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           float si = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            Wq[e] = fl[4 * q + e] * X.cr[4 * q + e];
+            Wq[e] = fl[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
             vj[e] = *reinterpret_cast<const float*>(aggb + X.oj[4 * q + e]);
             si += X.xj[4 * q + e] * Wq[e];
           }
@@ -1038,14 +1035,23 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16(), acc2 = zero16();
         {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
           const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
           const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(ph + 16 * s);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(pl + 16 * s);
-            mfma_split(ah, al, b1h[s], b1l[s], acc1, acc2);
-          }
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            mfma_split(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
         FMD_STAMP(ts0)
         message(fl_prev);  // tile t-S (X holds its gathers)
@@ -1085,7 +1091,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 // =================================================================================================
 struct SegRegsB {             // consumer state of one tile (register r = 4q + e <-> entry 8q+4h+e)
   uint32_t oi[4], oj[16];
-  float cr[16];
   float xi[4], xj[16], gi[4], gj[16];
 };
 
@@ -1097,7 +1102,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   uint32_t* gwt = reinterpret_cast<uint32_t*>(smem);             // [32][LDA] packed (hi | lo << 16), same region
   float* red = smem + TILE_FLOATS + 128;                         // [4][32]
   float* cen_l = red + 128;                                      // [64] rbf centres
-  float* gx1 = cen_l + 64;                                       // [n][128]
+  float* b0_l = cen_l + 64;                                      // [128] filter layer-0 bias
+  float* gx1 = b0_l + 128;                                       // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
@@ -1108,6 +1114,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   if (NEED_GX1)
     for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 64) cen_l[tid] = a.centers[tid];
+  if (tid < 128) b0_l[tid] = a.b0[tid];
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
@@ -1122,7 +1129,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0], wth[8], wtl[8];
-      float b0r[16];
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
@@ -1133,8 +1139,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
         wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + s) * 64 + lane];
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
       // meta of the tile to stage next (lane = pair view)
       float d_n, c_n, dc_n, gd_n = 0.f;
       auto fetch = [&](int t) {
@@ -1162,25 +1166,29 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           for (int j = 0; j < 8; ++j) {
             const float diff = d - (j < 4 ? c0[j & 3] : c1[j & 3]);
             const float raw = __expf(a.gamma * diff * diff);
-            x[j] = raw * C;
-            xp[j] = raw * (2.0f * a.gamma * diff * C + dC);
+            x[j] = raw;          // z  = C G0 + b0,            G0 = W0 raw
+            xp[j] = raw * diff;  // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
           }
           f16x8 bh, bl, ph, pl;
           split8(x, bh, bl);
           split8(xp, ph, pl);
           mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
           mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
+          __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
         }
+        const float g2c = 2.0f * a.gamma * C;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_l + 32 * w + 8 * q + 4 * h);
           float t4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
-            const float hv = fmd_tanh_fast(z1[r] + z2[r] * SPLIT_INV + b0r[r]);
-            t4[e] = hv;
+            const float g0 = z1[r] + z2[r] * SPLIT_INV, g1 = p1[r] + p2[r] * SPLIT_INV;
+            const float hv = fmd_tanh_fast(C * g0 + b4[e]);
+            t4[e] = C * hv;  // the tile carries C h: the consumers' L1 then yields W = filt C
             hr_nx[r] = hv;
-            k1_nx[r] = (1.0f - hv * hv) * (p1[r] + p2[r] * SPLIT_INV);
+            k1_nx[r] = (1.0f - hv * hv) * (g2c * g1 + dC * g0);
           }
           split4(t4, hh[q], hl[q]);
         }
@@ -1211,25 +1219,22 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
         f32x16 u1 = zero16(), u2 = zero16();
         {
+          // packed gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
           const uint32_t* gp = gwt + c32 * LDA + 8 * h;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const u32x4 v0 = *reinterpret_cast<const u32x4*>(gp + 16 * s);
-            const u32x4 v1 = *reinterpret_cast<const u32x4*>(gp + 16 * s + 4);
-            u32x4 hi4, lo4;
-            hi4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x05040100u);
-            hi4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x05040100u);
-            hi4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x05040100u);
-            hi4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x05040100u);
-            lo4[0] = __builtin_amdgcn_perm(v0[1], v0[0], 0x07060302u);
-            lo4[1] = __builtin_amdgcn_perm(v0[3], v0[2], 0x07060302u);
-            lo4[2] = __builtin_amdgcn_perm(v1[1], v1[0], 0x07060302u);
-            lo4[3] = __builtin_amdgcn_perm(v1[3], v1[2], 0x07060302u);
+          u32x4 v0 = *reinterpret_cast<const u32x4*>(gp), v1 = *reinterpret_cast<const u32x4*>(gp + 4);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            u32x4 n0 = v0, n1 = v1;
+            if constexpr (s + 1 < 8) {
+              n0 = *reinterpret_cast<const u32x4*>(gp + 16 * (s + 1));
+              n1 = *reinterpret_cast<const u32x4*>(gp + 16 * (s + 1) + 4);
+            }
             f16x8 bh, bl;
-            __builtin_memcpy(&bh, &hi4, 16);
-            __builtin_memcpy(&bl, &lo4, 16);
+            unpack_frag(v0, v1, bh, bl);
             mfma_split(wth[s], wtl[s], bh, bl, u1, u2);
-          }
+            v0 = n0; v1 = n1;
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
         // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
         float g_rbf = 0.f, g_c = 0.f;
@@ -1266,15 +1271,12 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       char* gx1b = reinterpret_cast<char*>(gx1);
       SegRegsB X;
       uint32_t oj_m[16], oi_m[4];
-      float cr_m[16];
       auto fetch_meta = [&](int t) {
         const int base = min(t * 32, last_base);
         static_for<0, 4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
           oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
-          const f32x4 c = *reinterpret_cast<const f32x4*>(pcut + base + 8 * q + 4 * h);
-          cr_m[4 * q] = c[0]; cr_m[4 * q + 1] = c[1]; cr_m[4 * q + 2] = c[2]; cr_m[4 * q + 3] = c[3];
           oi_m[q] = poi[base + 8 * q + 4 * h];
         });
       };
@@ -1285,7 +1287,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
-            X.cr[4 * q + e] = cr_m[4 * q + e];
           }
         });
         static_for<0, 4>([&](auto qc) {
@@ -1307,14 +1308,23 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16(), acc2 = zero16();
         {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
           const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
           const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(ph + 16 * s);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(pl + 16 * s);
-            mfma_split(ah, al, b1h[s], b1l[s], acc1, acc2);
-          }
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            mfma_split(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
+            __builtin_amdgcn_sched_barrier(0);
+          });
         }
         f32x16 fl;
 #pragma unroll
@@ -1341,7 +1351,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             float si = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              Wq[e] = fl[4 * q + e] * X.cr[4 * q + e];
+              Wq[e] = fl[4 * q + e];  // already filt * C
               vj[e] = *reinterpret_cast<const float*>(gx1b + X.oj[4 * q + e]);
               si += X.gj[4 * q + e] * Wq[e];
             }
@@ -2086,8 +2096,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   FMD_CHECK_LAUNCH();
 
   const int ks0 = (desc->num_rbf + 1) / 2;
-  // [tile region 4352 floats][red 128][centres 64][aggregate rows]
-  const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + 128 + 64 + max_beads_per_mol * F) * sizeof(float);
+  // [tile region 4352 floats][red 128][centres 64][bias 128][aggregate rows]
+  const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + max_beads_per_mol * F) * sizeof(float);
   hipError_t he = ks0 <= 16 ? set_edge_attrs<16>(lds_edge)
                   : ks0 <= 25 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
   if (he != hipSuccess) return FMD_ELAUNCH;

@@ -6,7 +6,7 @@ GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:22
 qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
 <= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
 tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights, and no
-molecule larger than 284 beads (its aggregate must fit the 160 KB LDS).  Anything else returns
+molecule larger than 283 beads (its aggregate must fit the 160 KB LDS).  Anything else returns
 None here and GradientsOut uses the operator path.
 """
 from __future__ import annotations
@@ -18,7 +18,7 @@ import torch
 from . import _ffi
 from ._ffi import call, ptr, stream
 
-MAX_BEADS = 284
+MAX_BEADS = 283
 PREC_F32 = 0
 
 

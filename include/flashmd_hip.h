@@ -200,7 +200,7 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
                                    int64_t max_pairs_per_mol);
 /* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY, [1] = max pairs seen in one molecule,
  * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
-/* max_beads_per_mol: upper bound on beads of one molecule (<= 284: the per-molecule aggregate lives
+/* max_beads_per_mol: upper bound on beads of one molecule (<= 283: the per-molecule aggregate lives
  * in LDS; larger molecules return FMD_EUNSUPPORTED and take the operator path).
  * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
  *   multiples of 8 entries; A(A-1)/2 + 8A can never overflow.
