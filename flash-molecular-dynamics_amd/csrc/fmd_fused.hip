@@ -475,7 +475,8 @@ struct EdgeArgs {
   int64_t slab_stride;
   float gamma, rc;
   int cap, n_split;
-  unsigned long long* stamps;  // diagnostic builds only
+  unsigned long long* stamps;  // diagnostic builds only (forward kernels)
+  unsigned long long* stamps2; // diagnostic builds only (backward split kernel, middle block)
 };
 
 template <int KS0, bool STAMP>
@@ -1094,7 +1095,7 @@ struct SegRegsB {             // consumer state of one tile (register r = 4q + e
   float xi[4], xj[16], gi[4], gj[16];
 };
 
-template <int NS0, bool NEED_GX1, bool FIRST>
+template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -1124,7 +1125,15 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int ntiles = (np + 31) >> 5;
   const int S = a.n_split;
   const int last_base = (ntiles - 1) * 32;
+  unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // diagnostic build only
+#define FMD_STAMP(k)                                           \
+  if (STAMP) {                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    ts[k] += now_ - tprev;                                     \
+    tprev = now_;                                              \
+  }
   __syncthreads();
+  if (STAMP) tprev = __builtin_readcyclecounter();
   if (split < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
@@ -1214,8 +1223,11 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       __syncthreads();  // A(first)
       for (int t = split; t < ntiles; t += S) {
         compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+        FMD_STAMP(0)
         __syncthreads();     // B(t)
+        FMD_STAMP(1)
         __syncthreads();     // C(t): gW(t) visible
+        FMD_STAMP(2)
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
         f32x16 u1 = zero16(), u2 = zero16();
         {
@@ -1247,14 +1259,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         float tot = C_cu * g_rbf + dC_cu * g_c;
         tot += __shfl_xor(tot, 32, 64);
         if (h == 0) red[w * 32 + c32] = tot;
+        FMD_STAMP(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
+        FMD_STAMP(4)
         if (w == 0 && h == 0) {
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
           pgd[t * 32 + c32] = FIRST ? sum : gd_cu + sum;
         }
         put();               // hidden tiles of t+S
         rotate();
+        FMD_STAMP(5)
         __syncthreads();     // A(t+S)
+        FMD_STAMP(6)
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
@@ -1340,10 +1356,14 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           __builtin_memcpy(&gwp[r], &pk, 4);
         }
         asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
+        FMD_STAMP(0)
         __syncthreads();  // B(t): hidden tiles consumed
+        FMD_STAMP(1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gwt[tile_row(r, h) * LDA + col] = gwp[r];
+        FMD_STAMP(2)
         __syncthreads();  // C(t): gW visible
+        FMD_STAMP(3)
         if (NEED_GX1) {   // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j)
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -1365,11 +1385,19 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
         fill();           // X <- tile t+S
         fetch_meta(t + 2 * S);
+        FMD_STAMP(4)
         __syncthreads();  // D(t)
+        FMD_STAMP(5)
         __syncthreads();  // A(t+S)
+        FMD_STAMP(6)
       }
     }
   }
+  if (STAMP && lane == 0) {
+    unsigned long long* o = a.stamps2 + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + w) * 16 + (producer ? 8 : 0);
+    for (int k = 0; k < 7; ++k) o[k] = ts[k];
+  }
+#undef FMD_STAMP
   if (NEED_GX1) {
     __syncthreads();
     float* out = a.slabs + split * a.slab_stride + a0 * F;
@@ -1853,7 +1881,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   if (tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
 }
 
-void* g_stamp_buffer = nullptr;  // set by fmd_debug_set_stamp_buffer (diagnostics, never in timed runs)
+void* g_stamp_buffer = nullptr;
+void* g_stamp_buffer2 = nullptr;  // set by fmd_debug_set_stamp_buffer (diagnostics, never in timed runs)
 
 int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -1950,10 +1979,11 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       else edge_bwd_kernel<KS0, false, false><<<grid, 256, lds, s>>>(ea);
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
-      if (need && first) edge_bwd_split_kernel<NS0, true, true><<<grid, 512, lds, s>>>(ea);
-      else if (need) edge_bwd_split_kernel<NS0, true, false><<<grid, 512, lds, s>>>(ea);
-      else if (first) edge_bwd_split_kernel<NS0, false, true><<<grid, 512, lds, s>>>(ea);
-      else edge_bwd_split_kernel<NS0, false, false><<<grid, 512, lds, s>>>(ea);
+      if (need && first) edge_bwd_split_kernel<NS0, true, true, false><<<grid, 512, lds, s>>>(ea);
+      else if (need && ea.stamps2) edge_bwd_split_kernel<NS0, true, false, true><<<grid, 512, lds, s>>>(ea);
+      else if (need) edge_bwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(ea);
+      else if (first) edge_bwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(ea);
+      else edge_bwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(ea);
     }
   }
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
@@ -1992,16 +2022,19 @@ hipError_t set_edge_attrs(size_t lds) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   constexpr int NS0 = (2 * KS0 + 15) / 16;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, true>,
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false>,
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, true, false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, true>,
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false, false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, false>,
+  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, true, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, false, false>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
@@ -2119,6 +2152,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);
+    ea.stamps2 = reinterpret_cast<unsigned long long*>(g_stamp_buffer2);
     if (ks0 <= 16) return run_edges<16>(desc, fwd, l, L, ea, egrid, lds_edge, s);
     if (ks0 <= 25) return run_edges<25>(desc, fwd, l, L, ea, egrid, lds_edge, s);
     return run_edges<32>(desc, fwd, l, L, ea, egrid, lds_edge, s);
@@ -2216,6 +2250,11 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
 // the stamped build of the forward pair kernel; NULL (default) selects the normal kernels.
 extern "C" int fmd_debug_set_stamp_buffer(void* device_buffer) {
   g_stamp_buffer = device_buffer;
+  return FMD_OK;
+}
+// same for the backward split kernel (middle blocks): [workgroups][4 slices][16] uint64
+extern "C" int fmd_debug_set_stamp_buffer_bwd(void* device_buffer) {
+  g_stamp_buffer2 = device_buffer;
   return FMD_OK;
 }
 

@@ -43,6 +43,7 @@ SIGNATURES = {
     "fmd_schnet_kernel_name": (ctypes.c_char_p, [P, I32]),
     "fmd_schnet_energy_forces_timed": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, I64]),
     "fmd_debug_set_stamp_buffer": (I32, [P]),
+    "fmd_debug_set_stamp_buffer_bwd": (I32, [P]),
     "fmd_langevin_pre": (I32, [P, P, P, P, P, P, I64, F32, F32, F32, P]),
     "fmd_langevin_post": (I32, [P, P, P, I64, F32, P]),
     "fmd_pt_swap_local": (I32, [P, P, P, P, P, P, I64, I64, P]),

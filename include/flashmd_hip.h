@@ -227,6 +227,8 @@ int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* pack
 /* Diagnostics only: device buffer [workgroups][4][6] of uint64 receiving per-phase cycle totals from
  * the stamped build of the forward pair kernel (NULL restores the normal kernels). */
 int fmd_debug_set_stamp_buffer(void* device_buffer);
+/* same for the backward pair kernel of the middle blocks: [workgroups][4][16] uint64 */
+int fmd_debug_set_stamp_buffer_bwd(void* device_buffer);
 
 /* ---------------------------------------------------------------------------------------------
  * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).
