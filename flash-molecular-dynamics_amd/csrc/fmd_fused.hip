@@ -181,6 +181,51 @@ __device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo
     lo[2 * j] = (_Float16)l[0]; lo[2 * j + 1] = (_Float16)l[1];
   }
 }
+// ---- packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two values per VALU slot):
+// the producers of the split pair kernels are VALU-issue bound, so their arithmetic is written on pairs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) {
+  return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+}
+// tanh = 1 - 2 rcp(e^{2x} + 1) on a pair (see fmd_tanh_fast)
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
+  const f32x2 e = exp2_2(x * splat2(2.0f * LOG2E)) + splat2(1.0f);
+  const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return splat2(1.0f) - splat2(2.0f) * rc;
+}
+// one pair -> packed hi (2 halves) and lo (2 halves) words
+__device__ __forceinline__ void split_pair(f32x2 x, uint32_t& hi, uint32_t& lo) {
+  const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+  const f32x2 xs = x * splat2(SPLIT_SCALE);  // (x - h) 2048 as x 2048 - h 2048: v_fma_mix reads the half directly
+  const hv2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -SPLIT_SCALE, xs[0]),
+                                           __builtin_fmaf((float)h[1], -SPLIT_SCALE, xs[1]));
+  __builtin_memcpy(&hi, &h, 4);
+  __builtin_memcpy(&lo, &l, 4);
+}
+// raw Gaussians of one k-step (8 centres of this lane half) as split fragments; with WITH_DIFF also
+// raw * (d - centre), the operand of z' = W0 . d(rbf)/dd.  gl = gamma * log2(e).
+template <bool WITH_DIFF>
+__device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0, const f32x4& c1, f16x8& bh,
+                                              f16x8& bl, f16x8& ph, f16x8& pl) {
+  uint32_t xh[4], xl[4], qh[4], ql[4];
+  const f32x2 cc[4] = {f32x2{c0[0], c0[1]}, f32x2{c0[2], c0[3]}, f32x2{c1[0], c1[1]}, f32x2{c1[2], c1[3]}};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 diff = splat2(d) - cc[j];
+    const f32x2 raw = exp2_2((diff * diff) * splat2(gl));
+    split_pair(raw, xh[j], xl[j]);
+    if (WITH_DIFF) split_pair(raw * diff, qh[j], ql[j]);
+  }
+  __builtin_memcpy(&bh, xh, 16);
+  __builtin_memcpy(&bl, xl, 16);
+  if (WITH_DIFF) {
+    __builtin_memcpy(&ph, qh, 16);
+    __builtin_memcpy(&pl, ql, 16);
+  }
+}
+
 // acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
 __device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
                                            const f16x8& bl, f32x16& acc1, f32x16& acc2) {
@@ -901,16 +946,17 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0];
-      float cen[8 * NS0], b0r[16];
+      f32x4 cen[2 * NS0], b0r[4];
+      const float gl = a.gamma * LOG2E;
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
         a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cen[8 * s + j] = a.centers[16 * s + 8 * h + j];
+        cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
+        cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) b0r[r] = a.b0[32 * w + tile_row(r, h)];
+      for (int q = 0; q < 4; ++q) b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h);
       float d_n = pdist[min(split * 32, last_base) + c32], c_n = pcut[min(split * 32, last_base) + c32];
       f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
       auto compute = [&](int t_next) {
@@ -921,24 +967,23 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         f32x16 acc1 = zero16(), acc2 = zero16();
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
-          float x[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float diff = d - cen[8 * s + j];
-            x[j] = __expf(a.gamma * diff * diff);  // C is a per-pair (per-lane) scalar: applied to the sums
-          }
-          f16x8 bh, bl;
-          split8(x, bh, bl);
+          f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
+          rbf_fragments<false>(d, gl, cen[2 * s], cen[2 * s + 1], bh, bl, ph, pl);
           mfma_split(a0h[s], a0l[s], bh, bl, acc1, acc2);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float t4[4];
+          uint32_t th[2], tl[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int ep = 0; ep < 2; ++ep) {
+            const int r = 4 * q + 2 * ep;
             // z = C (W0 raw) + b0 ; the tile carries C tanh(z): the consumers' L1 then yields W = filt C
-            t4[e] = C * fmd_tanh_fast(C * (acc1[4 * q + e] + acc2[4 * q + e] * SPLIT_INV) + b0r[4 * q + e]);
-          split4(t4, hh[q], hl[q]);
+            const f32x2 g0 = f32x2{acc1[r], acc1[r + 1]} + f32x2{acc2[r], acc2[r + 1]} * splat2(SPLIT_INV);
+            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b0r[q][2 * ep], b0r[q][2 * ep + 1]});
+            split_pair(splat2(C) * hv, th[ep], tl[ep]);
+          }
+          __builtin_memcpy(&hh[q], th, 8);
+          __builtin_memcpy(&hl[q], tl, 8);
         }
         // pin the computation in front of the barrier that follows
 #pragma unroll
@@ -1138,11 +1183,19 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0], wth[8], wtl[8];
+      // The W0 fragments are only used while a tile is staged and the W1^T fragments only in the
+      // reduction; the reduction is the register peak, so the lo half of W0 is re-read (L1/L2) after
+      // every reduction instead of being held across it.
+      const f16x8* a0l_p = reinterpret_cast<const f16x8*>(a.q0l) + w * 4 * 64 + lane;
+      auto load_a0l = [&]() {
+        int off = 0;
+        asm volatile("" : "+v"(off));  // not loop invariant as far as the compiler can tell
 #pragma unroll
-      for (int s = 0; s < NS0; ++s) {
-        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
-      }
+        for (int s = 0; s < NS0; ++s) a0l[s] = a0l_p[off + s * 64];
+      };
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+      load_a0l();
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
@@ -1159,28 +1212,23 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       };
       // staged tile ("nx") and tile whose reduction is pending ("cu")
       f16x4 hh[4], hl[4];
-      float hr_nx[16], k1_nx[16], C_nx = 0.f, dC_nx = 0.f, gd_nx = 0.f;
-      float hr_cu[16], k1_cu[16], C_cu = 0.f, dC_cu = 0.f, gd_cu = 0.f;
+      // k = d(message weight)/dd per unit u: C (1-h^2) z' + C' h   (one array: registers are tight)
+      float k_nx[16], gd_nx = 0.f;
+      float k_cu[16], gd_cu = 0.f;
+      const float gl = a.gamma * LOG2E;
       auto compute = [&](int t_fetch) {
         const float d = d_n, C = c_n, dC = dc_n;
-        C_nx = C; dC_nx = dC; gd_nx = gd_n;
+        gd_nx = gd_n;
         fetch(t_fetch);
         f32x16 z1 = zero16(), z2 = zero16(), p1 = zero16(), p2 = zero16();
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
           const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
-          float x[8], xp[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float diff = d - (j < 4 ? c0[j & 3] : c1[j & 3]);
-            const float raw = __expf(a.gamma * diff * diff);
-            x[j] = raw;          // z  = C G0 + b0,            G0 = W0 raw
-            xp[j] = raw * diff;  // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
-          }
+          // z  = C G0 + b0,            G0 = W0 raw
+          // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
           f16x8 bh, bl, ph, pl;
-          split8(x, bh, bl);
-          split8(xp, ph, pl);
+          rbf_fragments<true>(d, gl, c0, c1, bh, bl, ph, pl);
           mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
           mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
           __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
@@ -1189,17 +1237,21 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_l + 32 * w + 8 * q + 4 * h);
-          float t4[4];
+          uint32_t th[2], tl[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e;
-            const float g0 = z1[r] + z2[r] * SPLIT_INV, g1 = p1[r] + p2[r] * SPLIT_INV;
-            const float hv = fmd_tanh_fast(C * g0 + b4[e]);
-            t4[e] = C * hv;  // the tile carries C h: the consumers' L1 then yields W = filt C
-            hr_nx[r] = hv;
-            k1_nx[r] = (1.0f - hv * hv) * (g2c * g1 + dC * g0);
+          for (int ep = 0; ep < 2; ++ep) {
+            const int r = 4 * q + 2 * ep;
+            const f32x2 g0 = f32x2{z1[r], z1[r + 1]} + f32x2{z2[r], z2[r + 1]} * splat2(SPLIT_INV);
+            const f32x2 g1 = f32x2{p1[r], p1[r + 1]} + f32x2{p2[r], p2[r + 1]} * splat2(SPLIT_INV);
+            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
+            split_pair(splat2(C) * hv, th[ep], tl[ep]);  // the tile carries C h: L1 then yields W = filt C
+            const f32x2 kk = splat2(C) * ((splat2(1.0f) - hv * hv) * (splat2(g2c) * g1 + splat2(dC) * g0)) +
+                             splat2(dC) * hv;
+            k_nx[r] = kk[0];
+            k_nx[r + 1] = kk[1];
           }
-          split4(t4, hh[q], hl[q]);
+          __builtin_memcpy(&hh[q], th, 8);
+          __builtin_memcpy(&hl[q], tl, 8);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
@@ -1213,8 +1265,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       };
       auto rotate = [&]() {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { hr_cu[r] = hr_nx[r]; k1_cu[r] = k1_nx[r]; }
-        C_cu = C_nx; dC_cu = dC_nx; gd_cu = gd_nx;
+        for (int r = 0; r < 16; ++r) k_cu[r] = k_nx[r];
+        gd_cu = gd_nx;
       };
       fetch(split);
       compute(split + S);
@@ -1249,16 +1301,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           });
         }
         // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
-        float g_rbf = 0.f, g_c = 0.f;
+        float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float u = u1[r] + u2[r] * SPLIT_INV;
-          g_c += u * hr_cu[r];
-          g_rbf += u * k1_cu[r];
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 pr = (f32x2{u1[r], u1[r + 1]} + f32x2{u2[r], u2[r + 1]} * splat2(SPLIT_INV)) *
+                           f32x2{k_cu[r], k_cu[r + 1]};
+          tot += pr[0] + pr[1];
         }
-        float tot = C_cu * g_rbf + dC_cu * g_c;
         tot += __shfl_xor(tot, 32, 64);
         if (h == 0) red[w * 32 + c32] = tot;
+        __builtin_amdgcn_sched_barrier(0);
+        load_a0l();  // lands while the barriers below are crossed
+        __builtin_amdgcn_sched_barrier(0);
         FMD_STAMP(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
         FMD_STAMP(4)
