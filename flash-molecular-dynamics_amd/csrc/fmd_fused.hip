@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
-  uint32_t* gwt = reinterpret_cast<uint32_t*>(smem);             // [32][LDA] packed (hi | lo << 16), same region
+  // the gW tile reuses the two fp16 tiles (hi, lo), [pair][feature]
   float* red = smem + TILE_FLOATS + 128;                         // [4][32]
   float* cen_l = red + 128;                                      // [64] rbf centres
   float* b0_l = cen_l + 64;                                      // [128] filter layer-0 bias
@@ -1183,19 +1183,11 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0], wth[8], wtl[8];
-      // The W0 fragments are only used while a tile is staged and the W1^T fragments only in the
-      // reduction; the reduction is the register peak, so the lo half of W0 is re-read (L1/L2) after
-      // every reduction instead of being held across it.
-      const f16x8* a0l_p = reinterpret_cast<const f16x8*>(a.q0l) + w * 4 * 64 + lane;
-      auto load_a0l = [&]() {
-        int off = 0;
-        asm volatile("" : "+v"(off));  // not loop invariant as far as the compiler can tell
 #pragma unroll
-        for (int s = 0; s < NS0; ++s) a0l[s] = a0l_p[off + s * 64];
-      };
-#pragma unroll
-      for (int s = 0; s < NS0; ++s) a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-      load_a0l();
+      for (int s = 0; s < NS0; ++s) {
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+      }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
@@ -1255,6 +1247,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
+        // ... and the k array too: left alone, the compiler sinks its arithmetic behind the reduction
+        // and carries both accumulators of G1 and the hidden values (48 registers) across it instead
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(k_nx[r]));
       };
       auto put = [&]() {
 #pragma unroll
@@ -1283,20 +1279,19 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
         f32x16 u1 = zero16(), u2 = zero16();
         {
-          // packed gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
-          const uint32_t* gp = gwt + c32 * LDA + 8 * h;
-          u32x4 v0 = *reinterpret_cast<const u32x4*>(gp), v1 = *reinterpret_cast<const u32x4*>(gp + 4);
+          // gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
+          const _Float16* gph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* gpl = hid_lo + c32 * LDH + 8 * h;
+          f16x8 bh = *reinterpret_cast<const f16x8*>(gph), bl = *reinterpret_cast<const f16x8*>(gpl);
           static_for<0, 8>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            u32x4 n0 = v0, n1 = v1;
+            f16x8 nh = bh, nl = bl;
             if constexpr (s + 1 < 8) {
-              n0 = *reinterpret_cast<const u32x4*>(gp + 16 * (s + 1));
-              n1 = *reinterpret_cast<const u32x4*>(gp + 16 * (s + 1) + 4);
+              nh = *reinterpret_cast<const f16x8*>(gph + 16 * (s + 1));
+              nl = *reinterpret_cast<const f16x8*>(gpl + 16 * (s + 1));
             }
-            f16x8 bh, bl;
-            unpack_frag(v0, v1, bh, bl);
             mfma_split(wth[s], wtl[s], bh, bl, u1, u2);
-            v0 = n0; v1 = n1;
+            bh = nh; bl = nl;
             __builtin_amdgcn_sched_barrier(0);
           });
         }
@@ -1310,9 +1305,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
         tot += __shfl_xor(tot, 32, 64);
         if (h == 0) red[w * 32 + c32] = tot;
-        __builtin_amdgcn_sched_barrier(0);
-        load_a0l();  // lands while the barriers below are crossed
-        __builtin_amdgcn_sched_barrier(0);
         FMD_STAMP(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
         FMD_STAMP(4)
@@ -1399,8 +1391,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         f32x16 fl;
 #pragma unroll
         for (int r = 0; r < 16; ++r) fl[r] = acc1[r] + acc2[r] * SPLIT_INV;
-        // gW = x1[i] g[j] + x1[j] g[i], split and packed (hi | lo << 16)
-        uint32_t gwp[16];
+        // gW = x1[i] g[j] + x1[j] g[i], split (register = hi | lo << 16)
+        f16x2 gwp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float gw = X.xi[r >> 2] * X.gj[r] + X.xj[r] * X.gi[r >> 2];
@@ -1410,14 +1402,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           __builtin_memcpy(&gwp[r], &pk, 4);
         }
         asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
-        FMD_STAMP(0)
-        __syncthreads();  // B(t): hidden tiles consumed
-        FMD_STAMP(1)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gwt[tile_row(r, h) * LDA + col] = gwp[r];
-        FMD_STAMP(2)
-        __syncthreads();  // C(t): gW visible
-        FMD_STAMP(3)
+        // The aggregate update and the refill of X need nothing from the producers: they run here,
+        // while the producers are still staging the next tile, not between the later barriers.
         if (NEED_GX1) {   // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j)
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -1437,9 +1423,20 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             *reinterpret_cast<float*>(gx1b + X.oi[q]) = cval + si;
           });
         }
+        FMD_STAMP(0)
         fill();           // X <- tile t+S
         fetch_meta(t + 2 * S);
         FMD_STAMP(4)
+        __syncthreads();  // B(t): hidden tiles consumed
+        FMD_STAMP(1)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // ds_write_b16 of each half
+          hid_hi[tile_row(r, h) * LDH + col] = gwp[r][0];
+          hid_lo[tile_row(r, h) * LDH + col] = gwp[r][1];
+        }
+        FMD_STAMP(2)
+        __syncthreads();  // C(t): gW visible
+        FMD_STAMP(3)
         __syncthreads();  // D(t)
         FMD_STAMP(5)
         __syncthreads();  // A(t+S)

@@ -17,7 +17,7 @@ eng.energy_forces(pos, types, ptr, 269)
 torch.cuda.synchronize()
 _ffi.lib().fmd_debug_set_stamp_buffer_bwd(None)
 b = buf.view(256,4,16).double().cpu()
-names=['C: L1+gW math','C: wait B','C: gW write','C: wait C','C: gx1 RMW+fill+fetch','C: wait D','C: wait A','-',
+names=['C: L1+gW math+gx1 RMW','C: wait B','C: gW write','C: wait C','C: fill+fetch','C: wait D','C: wait A','-',
        'P: compute','P: wait B','P: wait C','P: u+reduce','P: wait D','P: put+rotate','P: wait A','-']
 tc = b[...,:8].sum(-1).mean().item()/130
 print('tile cycles (consumer view)', tc)
