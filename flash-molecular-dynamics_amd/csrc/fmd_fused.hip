@@ -6,12 +6,14 @@
 //  * the radius graph is symmetric and the filter W_ij = filt(d_ij) * C(d_ij) depends on the pair
 //    only, so work is organised over UNDIRECTED pairs i<j: the filter network runs once per pair and
 //    feeds both directions (half the MFMA work of a per-edge formulation, same arithmetic);
-//  * one workgroup (4 waves, one per SIMD) owns a share of one molecule's pair tiles (32 pairs);
-//    wave w owns output features [32w, 32w+32): its weight slices live in VGPRs for the whole
-//    kernel, the 32x128 hidden tile is exchanged through one 16.9 KB LDS buffer, and its slice of the
-//    per-molecule aggregate (<= 288 beads x 32 features) stays in LDS until the final flush.  Every
-//    aggregate element is touched by exactly one wave in program order => bit-reproducible sums;
-//  * all contractions are exact fp32 on v_mfma_f32_32x32x2_f32 (precision FMD_PREC_F32);
+//  * one workgroup owns a share of one molecule's pair tiles (32 pairs) and keeps the molecule's
+//    aggregate (<= 283 beads x 128 features, fp32) in LDS until one final flush; 8 waves, specialised:
+//    producers (rbf, filter layer 0, tanh -> hidden tile in LDS) and consumers (filter layer 1, row
+//    gathers, aggregate update), each owning a 32-feature slice whose weight fragments live in VGPRs.
+//    Every aggregate element is touched by exactly one wave in program order => bit-reproducible sums;
+//  * contractions: precision FMD_PREC_F32 = split-operand f16 MFMA (x = hi + lo/2048, three products,
+//    fp32 accumulation, 2e-7 = the error of the fp32 MFMA at 3/16 of its cycles);
+//    FMD_PREC_F32_MFMA = exact fp32 on v_mfma_f32_32x32x2_f32 (the 4-wave / wave-specialised fp32 kernels);
 //  * backward recomputes the filter instead of storing [E,F] tensors, and gets d/d(distance) from
 //    the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice GEMMs), so the only
 //    per-pair quantity that reaches HBM is one float (dE/dd) per pair.

@@ -19,7 +19,9 @@ from . import _ffi
 from ._ffi import call, ptr, stream
 
 MAX_BEADS = 283
-PREC_F32 = 0
+# fmd_schnet_desc.precision (include/flashmd_hip.h): both are fp32-grade (2e-7 per contraction)
+PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, the fast default
+              "f32_mfma": 2}   # FMD_PREC_F32_MFMA: exact fp32 MFMA kernels
 
 
 def _linears(mlp):
@@ -29,7 +31,7 @@ def _linears(mlp):
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0):
+    def __init__(self, model, n_split: int = 0, precision: str = "f32"):
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -63,7 +65,9 @@ class FusedSchNetEngine:
         for k in range(4):
             d.out_width[k] = outs[k].out_features if k < len(outs) else 0
         d.embedding_size = model.embedding_layer.num_embeddings
-        d.precision, d.n_split = PREC_F32, int(n_split)
+        if precision not in PRECISIONS:
+            raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
+        d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
         self.desc = d
 

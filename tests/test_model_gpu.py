@@ -128,6 +128,28 @@ def test_fused_engine_is_the_path_taken_and_deterministic(params):
         assert _relerr(e3, f3, e_o.numpy(), f_o.numpy())[1] < 1e-4
 
 
+def test_fused_engine_exact_fp32_mfma_kernels(params, golden_dir):
+    """precision="f32_mfma" (FMD_PREC_F32_MFMA): the exact-fp32 MFMA kernels meet the same budget and agree
+    with the split-operand default to fp32 rounding."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    z = np.load(os.path.join(golden_dir, "case_1enh_2x269.npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]).to(DEV) for k in ("pos", "types", "ptr"))
+    model = S.model_from_params(params).to(DEV)
+    out = {}
+    for prec in ("f32", "f32_mfma"):
+        e, f = engine.FusedSchNetEngine(model, precision=prec).energy_forces(pos, types, ptr, 269)
+        re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+        print(f"precision={prec}: energy {re:.2e} forces {rf:.2e}")
+        assert re < 2e-5 and rf < 2e-5
+        out[prec] = (e, f)
+    rf = float((out["f32"][1] - out["f32_mfma"][1]).norm() / out["f32_mfma"][1].norm())
+    assert rf < 1e-5
+    with pytest.raises(ValueError):
+        engine.FusedSchNetEngine(model, precision="w16a16")
+
+
 def test_fused_engine_other_hyperparameters():
     """R = 64 / L = 2 / output widths [32, 16] / 2-linear output net / non-zero biases."""
     import flashmd_amd.schnet as S
