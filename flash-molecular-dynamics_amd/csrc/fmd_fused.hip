@@ -19,6 +19,7 @@
 //    per-pair quantity that reaches HBM is one float (dE/dd) per pair.
 #include <string.h>
 #include <type_traits>
+#include <vector>
 #include <stdlib.h>
 
 #include "fmd_common.h"
@@ -28,6 +29,7 @@ namespace {
 constexpr int F = 128;            // hidden = filters
 constexpr int LDA = 132;          // LDS row stride (floats) of a 32 x 128 operand tile
 constexpr int TILE_FLOATS = 32 * LDA;
+constexpr size_t MAX_LDS_BYTES = 160 * 1024;
 constexpr int MAX_LDS_ROWS = 283; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
 constexpr int SLICE = 4 * 64 * 64;  // floats of one packed 128x128 operand ([wave][k-step][lane])
 constexpr int P0_FLOATS = 4 * 32 * 64;
@@ -38,13 +40,14 @@ constexpr int P0_FLOATS = 4 * 32 * 64;
 struct BlockOff {
   int64_t p0, b0, p1, p1t, l1, l1t, l2, b2, l2t, l3, b3, l3t;
   int64_t q0h, q0l, q1h, q1l, q1th, q1tl;  // fp16 hi/lo split operands of the filter network
+  int64_t q0ch, q0cl;                      // W0 with column k scaled by (centre_k - cutoff/2): backward only
 };
 struct PackLayout {
   int64_t emb, centers, blocks, block_stride, outs, out_stride, total;
 };
 constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // [wave][k-step of 16][lane] x 8 halves (16 B), K padded to 64
 constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
-constexpr int64_t BLOCK_FLOATS = P0_FLOATS + F + 8 * (int64_t)SLICE + 2 * F + 2 * Q0_FLOATS + 4 * Q1_FLOATS;
+constexpr int64_t BLOCK_FLOATS = P0_FLOATS + F + 8 * (int64_t)SLICE + 2 * F + 4 * Q0_FLOATS + 4 * Q1_FLOATS;
 constexpr int64_t OUT_FLOATS = 2 * (int64_t)SLICE + F;
 
 PackLayout pack_layout(const fmd_schnet_desc* d) {
@@ -79,6 +82,8 @@ BlockOff block_off(const PackLayout& L, int l) {
   o.q1l = p; p += Q1_FLOATS;
   o.q1th = p; p += Q1_FLOATS;
   o.q1tl = p; p += Q1_FLOATS;
+  o.q0ch = p; p += Q0_FLOATS;
+  o.q0cl = p; p += Q0_FLOATS;
   return o;
 }
 
@@ -517,6 +522,9 @@ struct EdgeArgs {
   const float* p1;         // packed filter layer 1 (B operand)
   const float* p1t;        // packed filter layer 1 transposed (A operand of u)
   const float *q0h, *q0l, *q1h, *q1l, *q1th, *q1tl;  // fp16 hi/lo split operands (16-byte records)
+  const float *q0ch, *q0cl;                          // centre-weighted W0 (backward, shared-Gaussian form)
+  float c0;                                          // cutoff / 2
+  int nb;                                            // ceil(num_rbf / 8): half k-steps that hold Gaussians
   const float* centers;    // [64]
   float* slabs;            // [n_split][N,128] partial aggregates (fwd: agg, bwd: gx1)
   int64_t slab_stride;
@@ -1142,7 +1150,7 @@ struct SegRegsB {             // consumer state of one tile (register r = 4q + e
   float xi[4], xj[16], gi[4], gj[16];
 };
 
-template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP>
+template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP, bool SHARE>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -1151,7 +1159,11 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   float* red = smem + TILE_FLOATS + 128;                         // [4][32]
   float* cen_l = red + 128;                                      // [64] rbf centres
   float* b0_l = cen_l + 64;                                      // [128] filter layer-0 bias
-  float* gx1 = b0_l + 128;                                       // [n][128]
+  // SHARE: the Gaussians of a tile are computed once, by the consumers (consumer w: k-step w), and cross
+  // LDS as split fragments [half k-step][hi, lo][pair] x 16 B; the producers then run W0 and
+  // Wc = W0 diag(centre - c0) on the same fragments (W0 (raw (d - centre)) = (d - c0) W0 raw - Wc raw).
+  float* frag_l = b0_l + 128;                                    // [nb][2][32] x 16 B   (SHARE only)
+  float* gx1 = frag_l + (SHARE ? a.nb * 256 : 0);                // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
@@ -1184,11 +1196,15 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   if (split < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
-      f16x8 a0h[NS0], a0l[NS0], wth[8], wtl[8];
+      f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
         a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        if (SHARE) {
+          ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[(w * 4 + s) * 64 + lane];
+          acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
+        }
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -1217,17 +1233,28 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         f32x16 z1 = zero16(), z2 = zero16(), p1 = zero16(), p2 = zero16();
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
-          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
-          const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
+          f32x4 c0, c1;
+          if (!SHARE) {
+            c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
+            c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
+          }
           // z  = C G0 + b0,            G0 = W0 raw
           // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
           f16x8 bh, bl, ph, pl;
-          rbf_fragments<true>(d, gl, c0, c1, bh, bl, ph, pl);
-          mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
-          mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
+          if (SHARE) {  // p accumulates Gc = Wc raw
+            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
+            bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
+            mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
+            mfma_split(ach[s], acl[s], bh, bl, p1, p2);
+          } else {
+            rbf_fragments<true>(d, gl, c0, c1, bh, bl, ph, pl);
+            mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
+            mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
+          }
           __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
         }
-        const float g2c = 2.0f * a.gamma * C;
+        const float g2c = 2.0f * a.gamma * C, dm = d - a.c0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_l + 32 * w + 8 * q + 4 * h);
@@ -1236,7 +1263,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           for (int ep = 0; ep < 2; ++ep) {
             const int r = 4 * q + 2 * ep;
             const f32x2 g0 = f32x2{z1[r], z1[r + 1]} + f32x2{z2[r], z2[r + 1]} * splat2(SPLIT_INV);
-            const f32x2 g1 = f32x2{p1[r], p1[r + 1]} + f32x2{p2[r], p2[r + 1]} * splat2(SPLIT_INV);
+            f32x2 g1 = f32x2{p1[r], p1[r + 1]} + f32x2{p2[r], p2[r + 1]} * splat2(SPLIT_INV);
+            if (SHARE) g1 = splat2(dm) * g0 - g1;
             const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
             split_pair(splat2(C) * hv, th[ep], tl[ep]);  // the tile carries C h: L1 then yields W = filt C
             const f32x2 kk = splat2(C) * ((splat2(1.0f) - hv * hv) * (splat2(g2c) * g1 + splat2(dC) * g0)) +
@@ -1267,7 +1295,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         gd_cu = gd_nx;
       };
       fetch(split);
+      if (SHARE) __syncthreads();  // fragments of the first tile visible
       compute(split + S);
+      if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
       rotate();
       put();
       __syncthreads();  // A(first)
@@ -1335,8 +1365,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       char* gx1b = reinterpret_cast<char*>(gx1);
       SegRegsB X;
       uint32_t oj_m[16], oi_m[4];
+      float d_m = 0.f;  // SHARE: distance of pair c32 of the fetched tile
       auto fetch_meta = [&](int t) {
         const int base = min(t * 32, last_base);
+        if (SHARE) d_m = pdist[base + c32];
         static_for<0, 4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
@@ -1364,9 +1396,29 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           X.gj[r] = *reinterpret_cast<const float*>(gab + X.oj[r]);
         });
       };
+      // SHARE: Gaussians of one tile, k-step w of this wave, as split fragments in LDS
+      const float gl = a.gamma * LOG2E;
+      auto share_fragments = [&]() {  // of the tile whose meta were fetched last
+        if (w < NS0 && 2 * w + h < a.nb) {
+          const float d = d_m;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h);
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h + 4);
+          f16x8 bh, bl, ph, pl;
+          rbf_fragments<false>(d, gl, c0, c1, bh, bl, ph, pl);
+          const int blk = 2 * w + h;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
+        }
+      };
       fetch_meta(split);
       fill();
+      if (SHARE) share_fragments();
       fetch_meta(split + S);
+      if (SHARE) {
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+      }
       __syncthreads();  // A(first)
       for (int t = split; t < ntiles; t += S) {
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
@@ -1439,6 +1491,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_STAMP(2)
         __syncthreads();  // C(t): gW visible
         FMD_STAMP(3)
+        // the producers read fragments only while staging (between A and B): the tile they stage in the
+        // next iteration, t + 2S, is written here, in the consumers' idle window
+        if (SHARE) share_fragments();
         __syncthreads();  // D(t)
         FMD_STAMP(5)
         __syncthreads();  // A(t+S)
@@ -2032,11 +2087,23 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       else edge_bwd_kernel<KS0, false, false><<<grid, 256, lds, s>>>(ea);
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
-      if (need && first) edge_bwd_split_kernel<NS0, true, true, false><<<grid, 512, lds, s>>>(ea);
-      else if (need && ea.stamps2) edge_bwd_split_kernel<NS0, true, false, true><<<grid, 512, lds, s>>>(ea);
-      else if (need) edge_bwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(ea);
-      else if (first) edge_bwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(ea);
-      else edge_bwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(ea);
+      // shared-Gaussian form when its fragment region fits next to the aggregate (block 0 keeps none)
+      const size_t frag = (size_t)ea.nb * 1024;
+      const size_t lds_sh = need ? lds + frag : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag;
+      const char* mode_sh = getenv("FMD_EDGE_BWD_SHARE");  // experiments: "0" disables
+      const bool share = lds_sh <= MAX_LDS_BYTES && !(mode_sh && mode_sh[0] == '0');
+      if (share) {
+        if (need && first) edge_bwd_split_kernel<NS0, true, true, false, true><<<grid, 512, lds_sh, s>>>(ea);
+        else if (need && ea.stamps2) edge_bwd_split_kernel<NS0, true, false, true, true><<<grid, 512, lds_sh, s>>>(ea);
+        else if (need) edge_bwd_split_kernel<NS0, true, false, false, true><<<grid, 512, lds_sh, s>>>(ea);
+        else if (first) edge_bwd_split_kernel<NS0, false, true, false, true><<<grid, 512, lds_sh, s>>>(ea);
+        else edge_bwd_split_kernel<NS0, false, false, false, true><<<grid, 512, lds_sh, s>>>(ea);
+      } else {
+        if (need && first) edge_bwd_split_kernel<NS0, true, true, false, false><<<grid, 512, lds, s>>>(ea);
+        else if (need) edge_bwd_split_kernel<NS0, true, false, false, false><<<grid, 512, lds, s>>>(ea);
+        else if (first) edge_bwd_split_kernel<NS0, false, true, false, false><<<grid, 512, lds, s>>>(ea);
+        else edge_bwd_split_kernel<NS0, false, false, false, false><<<grid, 512, lds, s>>>(ea);
+      }
     }
   }
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
@@ -2075,20 +2142,24 @@ hipError_t set_edge_attrs(size_t lds) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   constexpr int NS0 = (2 * KS0 + 15) / 16;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, true, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, true, false, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, true, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, false, false, false>,
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void* plain[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false>};
+  for (const void* f : plain) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const void* shared[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true>};
+  for (const void* f : shared) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace
@@ -2125,6 +2196,14 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     memcpy(out + o.b3, b.lin_b, F * sizeof(float));
     pack_node(out + o.l3t, b.lin_w, F, F, true, split);
     pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false);
+    {  // Wc[f][k] = (centre_k - cutoff/2) W0[f][k]:  W0 (raw (d - centre)) = (d - cutoff/2) W0 raw - Wc raw
+      std::vector<float> wc((size_t)F * desc->num_rbf);
+      const float c0 = 0.5f * desc->cutoff;
+      for (int f = 0; f < F; ++f)
+        for (int k = 0; k < desc->num_rbf; ++k)
+          wc[(size_t)f * desc->num_rbf + k] = (centers[k] - c0) * b.f0_w[(size_t)f * desc->num_rbf + k];
+      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, 4, false);
+    }
     pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false);
     pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
   }
@@ -2202,6 +2281,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.p0 = pk + o.p0; ea.b0 = pk + o.b0; ea.p1 = pk + o.p1; ea.p1t = pk + o.p1t;
     ea.q0h = pk + o.q0h; ea.q0l = pk + o.q0l; ea.q1h = pk + o.q1h; ea.q1l = pk + o.q1l;
     ea.q1th = pk + o.q1th; ea.q1tl = pk + o.q1tl;
+    ea.q0ch = pk + o.q0ch; ea.q0cl = pk + o.q0cl; ea.c0 = 0.5f * desc->cutoff; ea.nb = (desc->num_rbf + 7) / 8;
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);
