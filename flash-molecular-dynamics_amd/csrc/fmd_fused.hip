@@ -2269,7 +2269,10 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
 
   const bool sp = desc->precision == FMD_PREC_F32;
   const int64_t n_tiles = (n_nodes + 31) / 32;
-  const unsigned node_grid = (unsigned)(n_tiles < 256 ? n_tiles : 256);
+  // node kernels: workgroups loop over 32-row tiles; FMD_NODE_GRID (experiments) overrides the grid
+  int64_t ng_max = 768;
+  if (const char* e = getenv("FMD_NODE_GRID")) ng_max = atoi(e) > 0 ? atoi(e) : 768;
+  const unsigned node_grid = (unsigned)(n_tiles < ng_max ? n_tiles : ng_max);
   const int64_t slab_stride = n_nodes * F;
   dim3 egrid((unsigned)split, (unsigned)n_mol);
 

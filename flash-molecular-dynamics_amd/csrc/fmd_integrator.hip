@@ -34,6 +34,18 @@ __global__ __launch_bounds__(256) void langevin_post_kernel(float* __restrict__ 
   v[i] = v[i] + 0.5f * dt * f[i] / masses[i / 3];      // B  (:169)
 }
 
+// velocity Verlet first half (reference simulation/velocity_verlet.py:38-41): v += .5 dt f/m ; x += dt v
+__global__ __launch_bounds__(256) void verlet_pre_kernel(float* __restrict__ x, float* __restrict__ v,
+                                                         const float* __restrict__ f,
+                                                         const float* __restrict__ masses, int64_t n3,
+                                                         float dt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  const float vh = v[i] + 0.5f * dt * f[i] / masses[i / 3];
+  x[i] = x[i] + dt * vh;
+  v[i] = vh;
+}
+
 // one workgroup per proposed pair; untouched when the pair was rejected
 __global__ __launch_bounds__(256) void pt_swap_kernel(float* __restrict__ x, float* __restrict__ v,
                                                       const int64_t* __restrict__ mol_a,
@@ -80,6 +92,17 @@ extern "C" int fmd_langevin_post(float* v, const float* f, const float* masses, 
   const int64_t n3 = n_nodes * 3;
   langevin_post_kernel<<<(unsigned)((n3 + 255) / 256), 256, 0, fmd_stream(stream)>>>(v, f, masses, n3,
                                                                                   dt);
+  FMD_CHECK_LAUNCH();
+  return FMD_OK;
+}
+
+extern "C" int fmd_verlet_pre(float* x, float* v, const float* f, const float* masses, int64_t n_nodes,
+                              float dt, void* stream) {
+  if (n_nodes < 0) return FMD_EINVAL;
+  if (n_nodes == 0) return FMD_OK;
+  if (!x || !v || !f || !masses) return FMD_EINVAL;
+  const int64_t n3 = n_nodes * 3;
+  verlet_pre_kernel<<<(unsigned)((n3 + 255) / 256), 256, 0, fmd_stream(stream)>>>(x, v, f, masses, n3, dt);
   FMD_CHECK_LAUNCH();
   return FMD_OK;
 }

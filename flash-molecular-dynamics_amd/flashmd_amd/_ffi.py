@@ -46,6 +46,7 @@ SIGNATURES = {
     "fmd_debug_set_stamp_buffer_bwd": (I32, [P]),
     "fmd_langevin_pre": (I32, [P, P, P, P, P, P, I64, F32, F32, F32, P]),
     "fmd_langevin_post": (I32, [P, P, P, I64, F32, P]),
+    "fmd_verlet_pre": (I32, [P, P, P, P, I64, F32, P]),
     "fmd_pt_swap_local": (I32, [P, P, P, P, P, P, I64, I64, P]),
 }
 

@@ -38,6 +38,12 @@ def langevin_post(v, f, masses, dt: float):
     call("fmd_langevin_post", ptr(v), ptr(f), ptr(masses), v.shape[0], float(dt), stream())
 
 
+def verlet_pre(x, v, f, masses, dt: float):
+    """in place: velocity-Verlet half kick + drift (reference simulation/velocity_verlet.py:38-41)"""
+    _ffi.require_gpu(x, v, f, masses)
+    call("fmd_verlet_pre", ptr(x), ptr(v), ptr(f), ptr(masses), x.shape[0], float(dt), stream())
+
+
 def pt_swap_local(x, v, mol_a, mol_b, accept, beta_mol, n_atoms: int):
     """In place swap of accepted replica pairs living in one batch (reference
     simulation/parallel_tempering.py:415-481): x[a]<->x[b], v[a]=v[b]*sqrt(beta_a/beta_b),
@@ -115,6 +121,28 @@ class LangevinSimulation:
                 subroutine(self)
         sync()
         return (n_timesteps - half) * self.n_sims / (time.perf_counter() - t0)
+
+
+class NVESimulation(LangevinSimulation):
+    """Microcanonical velocity-Verlet loop (reference simulation/velocity_verlet.py:12-62): same state,
+    start-up (Maxwell-Boltzmann velocities) and throughput loop as the Langevin class."""
+
+    def timestep(self):
+        if self.use_hip:
+            verlet_pre(self.x, self.v, self.f, self.masses, self.dt)
+            self.energy, self.f = self.force_fn(self.x)
+            langevin_post(self.v, self.f, self.masses, self.dt)
+            return
+        dt, m = self.dt, self.masses[:, None]
+        v = self.v + 0.5 * dt * self.f / m
+        self.x = self.x + dt * v
+        self.energy, self.f = self.force_fn(self.x)
+        self.v = v + 0.5 * dt * self.f / m
+
+    def kinetic_energy(self):
+        """per molecule, 0.5 sum m v^2"""
+        ke = 0.5 * self.masses * (self.v * self.v).sum(-1)
+        return ke.view(self.n_sims, self.n_atoms).sum(-1)
 
 
 def pt_pairs(n_betas: int, even: bool):

@@ -244,6 +244,10 @@ int fmd_langevin_pre(float* x, float* v, const float* f, const float* masses, co
                      void* stream);
 int fmd_langevin_post(float* v, const float* f, const float* masses, int64_t n_nodes, float dt,
                       void* stream);
+/* NVE velocity Verlet (simulation/velocity_verlet.py:38-45): pre: v += .5 dt f/m ; x += dt v.
+ * The second half-kick after the force call is fmd_langevin_post. */
+int fmd_verlet_pre(float* x, float* v, const float* f, const float* masses, int64_t n_nodes, float dt,
+                   void* stream);
 int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* mol_b,
                       const uint8_t* accept, const float* beta_mol, int64_t n_pairs, int64_t n_atoms,
                       void* stream);

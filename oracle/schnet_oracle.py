@@ -406,6 +406,12 @@ def langevin_baoab_post(v, f, masses, dt):
     return v + 0.5 * dt * f / masses[:, None]
 
 
+def velocity_verlet_pre(x, v, f, masses, dt):
+    """simulation/velocity_verlet.py:38-41: half kick, full drift."""
+    v = v + 0.5 * dt * f / masses[:, None]
+    return x + dt * v, v
+
+
 def pt_exchange_decisions(u_a, u_b, beta_a, beta_b, rand_u):
     """simulation/parallel_tempering.py:368-413: accept when rand < exp((U_a-U_b)(beta_a-beta_b))."""
     p = torch.exp((u_a - u_b) * (beta_a - beta_b))

@@ -246,6 +246,11 @@ def test_langevin_and_pt_swap(K):
     v2_ref = so.langevin_baoab_post(v_ref, f, masses, 0.004)
     simulate.langevin_post(V, f.to(DEV), masses.to(DEV), 0.004)
     assert rel(V.cpu(), v2_ref) < 1e-6
+    # NVE velocity Verlet first half (the second half-kick is langevin_post)
+    xv_ref, vv_ref = so.velocity_verlet_pre(x, v, f, masses, 0.004)
+    Xv, Vv = x.to(DEV).clone(), v.to(DEV).clone()
+    simulate.verlet_pre(Xv, Vv, f.to(DEV), masses.to(DEV), 0.004)
+    assert rel(Xv.cpu(), xv_ref) < 1e-6 and rel(Vv.cpu(), vv_ref) < 1e-6
     # swap molecules (0,2) accepted, (1,3) rejected
     mol_a, mol_b = torch.tensor([0, 1]), torch.tensor([2, 3])
     acc = torch.tensor([1, 0], dtype=torch.uint8)
