@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--beads", type=int, default=269)
     ap.add_argument("--num-rbf", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=3)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32_mfma", "w16a16"],
+                    help="f32 = BASELINE configs[1] (default, the judged line); w16a16 = configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -127,7 +129,8 @@ def main():
             if n_.endswith("bias"):
                 prm.uniform_(-0.1, 0.1)
     model = model.to(dev).eval()
-    eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")))
+    eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")),
+                                   precision=args.precision)
     names = eng.kernel_names()
 
     # every rank owns its own molecules (different seeds per rank): embarrassingly parallel shards
@@ -192,24 +195,35 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
         value = args.steps * args.batch * world / elapsed
+        prec = {
+            "f32": dict(dtype="f32", peak=PEAK_SPLIT3_TFLOPS, cfg="Langevin fp32 (BASELINE configs[1])",
+                        arith="fp32 storage and accumulation; filter-network and node GEMMs as split-operand "
+                              "f16 MFMA (x = hi + lo/2048, 3 products), error 2e-7 = fp32 MFMA grade",
+                        note="dense f16 MFMA peak (16 x 157.3) / 3 products per fp32-grade product; "
+                             "the exact-fp32 MFMA peak is 157.3"),
+            "f32_mfma": dict(dtype="f32", peak=PEAK_F32_MFMA_TFLOPS, cfg="Langevin fp32 (BASELINE configs[1])",
+                             arith="exact fp32 MFMA (v_mfma_f32_32x32x2_f32)", note="dense fp32 MFMA peak"),
+            "w16a16": dict(dtype="f16", peak=PEAK_F16_MFMA_TFLOPS, cfg="W16A16 (BASELINE configs[2])",
+                           arith="filter and output networks: fp16 operands, fp32 accumulation (reference "
+                                 "W16A16 mode); node linears fp32-grade", note="dense f16 MFMA peak (16 x 157.3)"),
+        }[args.precision]
         line = {
             "metric": "timestep*mol/s, CGSchNet 1ENH batch=128",
             "value": value, "unit": "timestep*mol/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": value / PUBLISHED_BASELINE,
-            "dtype": "f32", "data": "synthetic",  # fp32 in/out and accumulation; products via 3x f16 MFMA (2e-7)
-            "config": {"workload": "CGSchNet 1ENH batch=128 Langevin fp32 (BASELINE configs[1])",
-                       "arithmetic": "fp32 storage and accumulation; filter-network and node GEMMs as split-operand "
-                                     "f16 MFMA (x = hi + lo/2048, 3 products), error 2e-7 = fp32 MFMA grade",
+            "dtype": prec["dtype"], "data": "synthetic",
+            "config": {"workload": "CGSchNet 1ENH batch=128 " + prec["cfg"],
+                       "arithmetic": prec["arith"],
                        "molecules_per_gpu": args.batch, "beads_per_molecule": args.beads,
                        "directed_edges_per_gpu": n_edges, "num_rbf": R, "interaction_blocks": args.blocks,
                        "hidden": 128, "output_widths": [128, 64, 1], "cutoff": rc, "dt": 0.004,
                        "sharding": f"replica-sharded x{world}, no collective in the force path",
                        "baseline_note": "2861 = reference README (W16A16, real 1ENH, RTX PRO 6000)"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_SPLIT3_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_SPLIT3_TFLOPS, "traffic": traffic,
-                         "peak_note": "dense f16 MFMA peak (16 x 157.3) / 3 products per fp32-grade product; "
-                                      "the exact-fp32 MFMA peak is 157.3",
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": prec["peak"],
+                         "unit": "TFLOP/s", "frac": achieved / prec["peak"],
+                         "traffic": traffic if args.precision == "f32" else None,
+                         "peak_note": prec["note"],
                          "frac_of_exact_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": avg_ms[dom],
                          "launches_per_step": launches[dom]},

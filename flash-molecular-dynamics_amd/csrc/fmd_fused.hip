@@ -202,6 +202,22 @@ __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
   const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
   return splat2(1.0f) - splat2(2.0f) * rc;
 }
+// W16A16 forms (template flag HALF): operands are rounded to fp16 once (round to nearest even, as the
+// reference's .half()) and a product is the single hi.hi MFMA; the lo words/tiles/fragments are unused.
+template <bool HALF>
+__device__ __forceinline__ void mfma_prod(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                          f32x16& acc1, f32x16& acc2);
+template <bool HALF>
+__device__ __forceinline__ f32x2 comb2(const f32x16& a1, const f32x16& a2, int r) {
+  if (HALF) return f32x2{a1[r], a1[r + 1]};
+  return f32x2{a1[r], a1[r + 1]} + f32x2{a2[r], a2[r + 1]} * f32x2{1.0f / 2048.0f, 1.0f / 2048.0f};
+}
+__device__ __forceinline__ uint32_t half_pair(f32x2 x) {  // v_cvt_pk_f16_f32 (RTE)
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  uint32_t u;
+  __builtin_memcpy(&u, &h, 4);
+  return u;
+}
 // one pair -> packed hi (2 halves) and lo (2 halves) words
 __device__ __forceinline__ void split_pair(f32x2 x, uint32_t& hi, uint32_t& lo) {
   const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
@@ -213,7 +229,7 @@ __device__ __forceinline__ void split_pair(f32x2 x, uint32_t& hi, uint32_t& lo) 
 }
 // raw Gaussians of one k-step (8 centres of this lane half) as split fragments; with WITH_DIFF also
 // raw * (d - centre), the operand of z' = W0 . d(rbf)/dd.  gl = gamma * log2(e).
-template <bool WITH_DIFF>
+template <bool WITH_DIFF, bool HALF = false>
 __device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0, const f32x4& c1, f16x8& bh,
                                               f16x8& bl, f16x8& ph, f16x8& pl) {
   uint32_t xh[4], xl[4], qh[4], ql[4];
@@ -222,8 +238,14 @@ __device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0
   for (int j = 0; j < 4; ++j) {
     const f32x2 diff = splat2(d) - cc[j];
     const f32x2 raw = exp2_2((diff * diff) * splat2(gl));
-    split_pair(raw, xh[j], xl[j]);
-    if (WITH_DIFF) split_pair(raw * diff, qh[j], ql[j]);
+    if (HALF) {
+      xh[j] = half_pair(raw);
+      xl[j] = 0;
+      if (WITH_DIFF) { qh[j] = half_pair(raw * diff); ql[j] = 0; }
+    } else {
+      split_pair(raw, xh[j], xl[j]);
+      if (WITH_DIFF) split_pair(raw * diff, qh[j], ql[j]);
+    }
   }
   __builtin_memcpy(&bh, xh, 16);
   __builtin_memcpy(&bl, xl, 16);
@@ -233,6 +255,15 @@ __device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0
   }
 }
 
+template <bool HALF>
+__device__ __forceinline__ void mfma_prod(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                          f32x16& acc1, f32x16& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+  if (!HALF) {
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+  }
+}
 // acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
 __device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
                                            const f16x8& bl, f32x16& acc1, f32x16& acc2) {
@@ -320,6 +351,35 @@ __device__ __forceinline__ f32x16 gemm_rows(const float* lds_a, const float* __r
                                             int lane) {
   if (SPLIT) return gemm_rows_split(lds_a, pk, w, lane);
   return gemm_rows_packed(lds_a, pk, w, lane);
+}
+// W16A16 output network: tile elements are u32 = f16(x) (round to nearest even), the operand is the hi
+// record of the split form (= Linear.weight.half()), one MFMA per k-step
+__device__ __forceinline__ f32x16 gemm_rows_half(const float* lds_a, const float* pk, int w, int lane) {
+  asm volatile("" : "+s"(pk));
+  f32x16 acc = zero16();
+  const uint32_t* ap = reinterpret_cast<const uint32_t*>(lds_a) + (lane & 31) * LDA + 8 * (lane >> 5);
+  const f16x8* bh = reinterpret_cast<const f16x8*>(pk) + (int64_t)w * 8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(ap + 16 * s);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(ap + 16 * s + 4);
+    f16x8 ah, al;
+    unpack_frag(v0, v1, ah, al);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s * 64], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// rounds v to fp16 in place (the value later layers and the backward see) and stores it
+__device__ __forceinline__ void tile_store_half(float* buf, f32x16& v, int w, int lane) {
+  const int col = 32 * w + (lane & 31), h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const _Float16 hv = (_Float16)v[r];
+    v[r] = (float)hv;
+    uint16_t bits;
+    __builtin_memcpy(&bits, &hv, 2);
+    reinterpret_cast<uint32_t*>(buf)[tile_row(r, h) * LDA + col] = bits;
+  }
 }
 template <bool SPLIT>
 __device__ __forceinline__ f32x16 gemm_rows_nohoist(const float* lds_a, const float* pk, int w, int lane) {
@@ -922,7 +982,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
 // fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
 // edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
 // =================================================================================================
-template <int NS0, bool STAMP>  // NS0: k-steps of 16 covering the rbf index (ceil(R / 16))
+template <int NS0, bool STAMP, bool HALF>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -961,7 +1021,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
         cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
         cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
       }
@@ -978,8 +1038,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
           f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
-          rbf_fragments<false>(d, gl, cen[2 * s], cen[2 * s + 1], bh, bl, ph, pl);
-          mfma_split(a0h[s], a0l[s], bh, bl, acc1, acc2);
+          rbf_fragments<false, HALF>(d, gl, cen[2 * s], cen[2 * s + 1], bh, bl, ph, pl);
+          mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, acc1, acc2);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -988,9 +1048,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           for (int ep = 0; ep < 2; ++ep) {
             const int r = 4 * q + 2 * ep;
             // z = C (W0 raw) + b0 ; the tile carries C tanh(z): the consumers' L1 then yields W = filt C
-            const f32x2 g0 = f32x2{acc1[r], acc1[r + 1]} + f32x2{acc2[r], acc2[r + 1]} * splat2(SPLIT_INV);
+            const f32x2 g0 = comb2<HALF>(acc1, acc2, r);
             const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b0r[q][2 * ep], b0r[q][2 * ep + 1]});
-            split_pair(splat2(C) * hv, th[ep], tl[ep]);
+            if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
+            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
           }
           __builtin_memcpy(&hh[q], th, 8);
           __builtin_memcpy(&hl[q], tl, 8);
@@ -1003,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
-          *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+          if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
       compute(split + S);
@@ -1025,7 +1086,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
-        b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
       }
       const uint32_t col4 = (uint32_t)(32 * w + c32) * 4u;
       const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
@@ -1104,7 +1165,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
               aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
-            mfma_split(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -1114,7 +1175,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         fill();            // X <- tile t (meta fetched one tile ago; lands before the next update)
         fetch_meta(t + S);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r] + acc2[r] * SPLIT_INV;
+        for (int r = 0; r < 16; ++r) fl_prev[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
         asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
         FMD_STAMP(ts2)
         __syncthreads();  // B(t): hidden tiles consumed
@@ -1150,7 +1211,7 @@ struct SegRegsB {             // consumer state of one tile (register r = 4q + e
   float xi[4], xj[16], gi[4], gj[16];
 };
 
-template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP, bool SHARE>
+template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP, bool SHARE, bool HALF>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -1200,8 +1261,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-        a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
-        if (SHARE) {
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        if (SHARE && !HALF) {
           ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[(w * 4 + s) * 64 + lane];
           acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
         }
@@ -1209,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
-        wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + s) * 64 + lane];
+        if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + s) * 64 + lane];
       }
       // meta of the tile to stage next (lane = pair view)
       float d_n, c_n, dc_n, gd_n = 0.f;
@@ -1245,12 +1306,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
             bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
             bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
-            mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
-            mfma_split(ach[s], acl[s], bh, bl, p1, p2);
+            if (HALF) {  // W16A16: the second record holds f16(raw (d - centre)); no cancellation-prone Wc form
+              z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
+            } else {
+              mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
+              mfma_split(ach[s], acl[s], bh, bl, p1, p2);
+            }
           } else {
-            rbf_fragments<true>(d, gl, c0, c1, bh, bl, ph, pl);
-            mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
-            mfma_split(a0h[s], a0l[s], ph, pl, p1, p2);
+            rbf_fragments<true, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
+            mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, z1, z2);
+            mfma_prod<HALF>(a0h[s], a0l[s], ph, pl, p1, p2);
           }
           __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
         }
@@ -1262,11 +1328,13 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int ep = 0; ep < 2; ++ep) {
             const int r = 4 * q + 2 * ep;
-            const f32x2 g0 = f32x2{z1[r], z1[r + 1]} + f32x2{z2[r], z2[r + 1]} * splat2(SPLIT_INV);
-            f32x2 g1 = f32x2{p1[r], p1[r + 1]} + f32x2{p2[r], p2[r + 1]} * splat2(SPLIT_INV);
-            if (SHARE) g1 = splat2(dm) * g0 - g1;
+            const f32x2 g0 = comb2<HALF>(z1, z2, r);
+            f32x2 g1 = comb2<HALF>(p1, p2, r);
+            if (SHARE && !HALF) g1 = splat2(dm) * g0 - g1;
             const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
-            split_pair(splat2(C) * hv, th[ep], tl[ep]);  // the tile carries C h: L1 then yields W = filt C
+            // the tile carries C h: L1 then yields W = filt C
+            if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
+            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
             const f32x2 kk = splat2(C) * ((splat2(1.0f) - hv * hv) * (splat2(g2c) * g1 + splat2(dC) * g0)) +
                              splat2(dC) * hv;
             k_nx[r] = kk[0];
@@ -1286,7 +1354,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
-          *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+          if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
       auto rotate = [&]() {
@@ -1322,7 +1390,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               nh = *reinterpret_cast<const f16x8*>(gph + 16 * (s + 1));
               nl = *reinterpret_cast<const f16x8*>(gpl + 16 * (s + 1));
             }
-            mfma_split(wth[s], wtl[s], bh, bl, u1, u2);
+            mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
             bh = nh; bl = nl;
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -1331,7 +1399,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         float tot = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 pr = (f32x2{u1[r], u1[r + 1]} + f32x2{u2[r], u2[r + 1]} * splat2(SPLIT_INV)) *
+          const f32x2 pr = comb2<HALF>(u1, u2, r) *
                            f32x2{k_cu[r], k_cu[r + 1]};
           tot += pr[0] + pr[1];
         }
@@ -1356,7 +1424,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
-        b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
       }
       const int col = 32 * w + c32;
       const uint32_t col4 = (uint32_t)col * 4u;
@@ -1404,10 +1472,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h);
           const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h + 4);
           f16x8 bh, bl, ph, pl;
-          rbf_fragments<false>(d, gl, c0, c1, bh, bl, ph, pl);
+          rbf_fragments<HALF, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
           const int blk = 2 * w + h;
           *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
-          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
         }
       };
       fetch_meta(split);
@@ -1437,23 +1505,27 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
               aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
-            mfma_split(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });
         }
         f32x16 fl;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fl[r] = acc1[r] + acc2[r] * SPLIT_INV;
+        for (int r = 0; r < 16; ++r) fl[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
         // gW = x1[i] g[j] + x1[j] g[i], split (register = hi | lo << 16)
         f16x2 gwp[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float gw = X.xi[r >> 2] * X.gj[r] + X.xj[r] * X.gi[r >> 2];
-          const hv2 h1 = __builtin_amdgcn_cvt_pkrtz(gw, 0.0f);
-          const float rem = (gw - (float)h1[0]) * SPLIT_SCALE;
-          const hv2 pk = __builtin_amdgcn_cvt_pkrtz(gw, rem);
-          __builtin_memcpy(&gwp[r], &pk, 4);
+          if (HALF) {
+            gwp[r] = f16x2{(_Float16)gw, (_Float16)0.0f};
+          } else {
+            const hv2 h1 = __builtin_amdgcn_cvt_pkrtz(gw, 0.0f);
+            const float rem = (gw - (float)h1[0]) * SPLIT_SCALE;
+            const hv2 pk = __builtin_amdgcn_cvt_pkrtz(gw, rem);
+            __builtin_memcpy(&gwp[r], &pk, 4);
+          }
         }
         asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
         // The aggregate update and the refill of X need nothing from the producers: they run here,
@@ -1486,7 +1558,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // ds_write_b16 of each half
           hid_hi[tile_row(r, h) * LDH + col] = gwp[r][0];
-          hid_lo[tile_row(r, h) * LDH + col] = gwp[r][1];
+          if (!HALF) hid_lo[tile_row(r, h) * LDH + col] = gwp[r][1];
         }
         FMD_STAMP(2)
         __syncthreads();  // C(t): gW visible
@@ -1782,7 +1854,9 @@ struct NodeOutArgs {
   int64_t n_nodes;
 };
 
-template <int NUM_OUT, bool SPLIT>
+// HOUT: W16A16 output network (fp16 operands and stored activations, fp32 accumulation; reference
+// models/gptq.py:266-306 with the rounding points of SURVEY row A9)
+template <int NUM_OUT, bool SPLIT, bool HOUT>
 __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
@@ -1810,7 +1884,8 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
       const int64_t row = row0 + tile_row(r, h);
       acc[r] = row < a.n_nodes ? a.x[row * F + col] + (acc[r] + b3) : 0.f;
     }
-    tile_store<SPLIT>(bufA, acc, w, lane);
+    if (HOUT) tile_store_half(bufA, acc, w, lane);
+    else tile_store<SPLIT>(bufA, acc, w, lane);
     __syncthreads();
     // ---- output network forward (tanh hidden layers, last layer linear without bias)
     f32x16 hk[2];
@@ -1818,15 +1893,17 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     float* nxt = bufB;
 #pragma unroll
     for (int k = 0; k < NUM_OUT - 1; ++k) {
-      hk[k] = gemm_rows_nohoist<SPLIT>(cur, a.po[k], w, lane);
+      hk[k] = HOUT ? gemm_rows_half(cur, a.po[k], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.po[k], w, lane);
       const float bk = a.bo[k][col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh_fast(hk[k][r] + bk);
-      tile_store<SPLIT>(nxt, hk[k], w, lane);
+      if (HOUT) tile_store_half(nxt, hk[k], w, lane);  // hk <- f16(tanh): what the backward multiplies by
+      else tile_store<SPLIT>(nxt, hk[k], w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    const f32x16 e = gemm_rows_nohoist<SPLIT>(cur, a.po[NUM_OUT - 1], w, lane);
+    const f32x16 e = HOUT ? gemm_rows_half(cur, a.po[NUM_OUT - 1], w, lane)
+                          : gemm_rows_nohoist<SPLIT>(cur, a.po[NUM_OUT - 1], w, lane);
     if (col == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1838,19 +1915,21 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     f32x16 g;
 #pragma unroll
     for (int r = 0; r < 16; ++r) g[r] = col == 0 ? 1.0f : 0.0f;
-    tile_store<SPLIT>(nxt, g, w, lane);
+    if (HOUT) tile_store_half(nxt, g, w, lane);
+    else tile_store<SPLIT>(nxt, g, w, lane);
     __syncthreads();
     { float* tmp = cur; cur = nxt; nxt = tmp; }
 #pragma unroll
     for (int k = NUM_OUT - 1; k >= 1; --k) {
-      g = gemm_rows_nohoist<SPLIT>(cur, a.pot[k], w, lane);
+      g = HOUT ? gemm_rows_half(cur, a.pot[k], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.pot[k], w, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
-      tile_store<SPLIT>(nxt, g, w, lane);
+      if (HOUT) tile_store_half(nxt, g, w, lane);  // f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
+      else tile_store<SPLIT>(nxt, g, w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    g = gemm_rows_nohoist<SPLIT>(cur, a.pot[0], w, lane);
+    g = HOUT ? gemm_rows_half(cur, a.pot[0], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.pot[0], w, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
@@ -2056,7 +2135,8 @@ bool desc_ok(const fmd_schnet_desc* d) {
   for (int k = 0; k < d->num_out; ++k)
     if (d->out_width[k] < 1 || d->out_width[k] > F) return false;
   if (d->out_width[d->num_out - 1] != 1) return false;
-  if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_F32_MFMA) return false;
+  if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_F32_MFMA && d->precision != FMD_PREC_W16A16)
+    return false;
   if (d->embedding_size < 1) return false;
   return true;
 }
@@ -2074,8 +2154,9 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       else edge_fwd_ws_kernel<KS0, false><<<grid, 512, lds, s>>>(ea);
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
-      if (ea.stamps) edge_fwd_split_kernel<NS0, true><<<grid, 512, lds, s>>>(ea);
-      else edge_fwd_split_kernel<NS0, false><<<grid, 512, lds, s>>>(ea);
+      if (d->precision == FMD_PREC_W16A16) edge_fwd_split_kernel<NS0, false, true><<<grid, 512, lds, s>>>(ea);
+      else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false><<<grid, 512, lds, s>>>(ea);
+      else edge_fwd_split_kernel<NS0, false, false><<<grid, 512, lds, s>>>(ea);
     }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
@@ -2092,18 +2173,31 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       const size_t lds_sh = need ? lds + frag : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag;
       const char* mode_sh = getenv("FMD_EDGE_BWD_SHARE");  // experiments: "0" disables
       const bool share = lds_sh <= MAX_LDS_BYTES && !(mode_sh && mode_sh[0] == '0');
-      if (share) {
-        if (need && first) edge_bwd_split_kernel<NS0, true, true, false, true><<<grid, 512, lds_sh, s>>>(ea);
-        else if (need && ea.stamps2) edge_bwd_split_kernel<NS0, true, false, true, true><<<grid, 512, lds_sh, s>>>(ea);
-        else if (need) edge_bwd_split_kernel<NS0, true, false, false, true><<<grid, 512, lds_sh, s>>>(ea);
-        else if (first) edge_bwd_split_kernel<NS0, false, true, false, true><<<grid, 512, lds_sh, s>>>(ea);
-        else edge_bwd_split_kernel<NS0, false, false, false, true><<<grid, 512, lds_sh, s>>>(ea);
+      const bool half = d->precision == FMD_PREC_W16A16;
+#define FMD_BWD(N_, F_, T_, S_, H_) edge_bwd_split_kernel<NS0, N_, F_, T_, S_, H_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(ea)
+      if (share && half) {
+        if (need && first) FMD_BWD(true, true, false, true, true);
+        else if (need) FMD_BWD(true, false, false, true, true);
+        else if (first) FMD_BWD(false, true, false, true, true);
+        else FMD_BWD(false, false, false, true, true);
+      } else if (half) {
+        if (need && first) FMD_BWD(true, true, false, false, true);
+        else if (need) FMD_BWD(true, false, false, false, true);
+        else if (first) FMD_BWD(false, true, false, false, true);
+        else FMD_BWD(false, false, false, false, true);
+      } else if (share) {
+        if (need && first) FMD_BWD(true, true, false, true, false);
+        else if (need && ea.stamps2) FMD_BWD(true, false, true, true, false);
+        else if (need) FMD_BWD(true, false, false, true, false);
+        else if (first) FMD_BWD(false, true, false, true, false);
+        else FMD_BWD(false, false, false, true, false);
       } else {
-        if (need && first) edge_bwd_split_kernel<NS0, true, true, false, false><<<grid, 512, lds, s>>>(ea);
-        else if (need) edge_bwd_split_kernel<NS0, true, false, false, false><<<grid, 512, lds, s>>>(ea);
-        else if (first) edge_bwd_split_kernel<NS0, false, true, false, false><<<grid, 512, lds, s>>>(ea);
-        else edge_bwd_split_kernel<NS0, false, false, false, false><<<grid, 512, lds, s>>>(ea);
+        if (need && first) FMD_BWD(true, true, false, false, false);
+        else if (need) FMD_BWD(true, false, false, false, false);
+        else if (first) FMD_BWD(false, true, false, false, false);
+        else FMD_BWD(false, false, false, false, false);
       }
+#undef FMD_BWD
     }
   }
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
@@ -2123,10 +2217,13 @@ hipError_t set_edge_attrs(size_t lds) {
   e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false>,
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false, false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, true>,
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, true, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,
@@ -2142,19 +2239,27 @@ hipError_t set_edge_attrs(size_t lds) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   constexpr int NS0 = (2 * KS0 + 15) / 16;
-  const void* plain[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false>};
+  const void* plain[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, true, false, false, true>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, true>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, true>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, true>};
   for (const void* f : plain) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const void* shared[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, false, true, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true>};
+  const void* shared[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, true, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, true, false, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, true>};
   for (const void* f : shared) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -2174,7 +2279,8 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
   if (!desc_ok(desc) || !wt || !centers || !packed_host || !wt->embedding || !wt->blocks) return FMD_EINVAL;
   const PackLayout L = pack_layout(desc);
   float* out = reinterpret_cast<float*>(packed_host);
-  const bool split = desc->precision == FMD_PREC_F32;  // node operands in split (hi/lo fp16) form
+  // node operands in split (hi/lo fp16) form; W16A16 keeps lin1/lin2/lin fp32-grade like the reference
+  const bool split = desc->precision != FMD_PREC_F32_MFMA;
   memset(out, 0, L.total * sizeof(float));
   memcpy(out + L.emb, wt->embedding, (size_t)desc->embedding_size * F * sizeof(float));
   for (int k = 0; k < desc->num_rbf; ++k) out[L.centers + k] = centers[k];
@@ -2185,6 +2291,8 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     const BlockOff o = block_off(L, l);
     pack_p0(out + o.p0, b.f0_w, desc->num_rbf);
     memcpy(out + o.b0, b.f0_b, F * sizeof(float));
+    if (desc->precision == FMD_PREC_W16A16)  // the fp16 filter network carries its bias in fp16 (gptq.py:178-184)
+      for (int f = 0; f < F; ++f) out[o.b0 + f] = (float)(_Float16)out[o.b0 + f];
     pack_slice(out + o.p1, b.f1_w, F, F, false);
     pack_slice(out + o.p1t, b.f1_w, F, F, true);
     pack_node(out + o.l1, b.lin1_w, F, F, false, split);
@@ -2214,6 +2322,8 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     const int ow = desc->out_width[k];
     pack_node(base, wt->out_w[k], ow, in_w, false, split);
     if (wt->out_b[k]) memcpy(base + SLICE, wt->out_b[k], ow * sizeof(float));
+    if (desc->precision == FMD_PREC_W16A16)
+      for (int f = 0; f < F; ++f) base[SLICE + f] = (float)(_Float16)base[SLICE + f];
     pack_node(base + SLICE + F, wt->out_w[k], in_w, ow, true, split);  // (W^T)[o=in][k=out] = W[out][in]
     in_w = ow;
   }
@@ -2267,7 +2377,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
                   : ks0 <= 25 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
   if (he != hipSuccess) return FMD_ELAUNCH;
 
-  const bool sp = desc->precision == FMD_PREC_F32;
+  const bool sp = desc->precision != FMD_PREC_F32_MFMA;
   const int64_t n_tiles = (n_nodes + 31) / 32;
   // node kernels: workgroups loop over 32-row tiles; FMD_NODE_GRID (experiments) overrides the grid
   int64_t ng_max = 768;
@@ -2332,11 +2442,13 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
     ev_begin();
     if (desc->num_out == 3) {
-      if (sp) node_out_kernel<3, true><<<node_grid, 256, 0, s>>>(oa);
-      else node_out_kernel<3, false><<<node_grid, 256, 0, s>>>(oa);
+      if (desc->precision == FMD_PREC_W16A16) node_out_kernel<3, true, true><<<node_grid, 256, 0, s>>>(oa);
+      else if (sp) node_out_kernel<3, true, false><<<node_grid, 256, 0, s>>>(oa);
+      else node_out_kernel<3, false, false><<<node_grid, 256, 0, s>>>(oa);
     } else {
-      if (sp) node_out_kernel<2, true><<<node_grid, 256, 0, s>>>(oa);
-      else node_out_kernel<2, false><<<node_grid, 256, 0, s>>>(oa);
+      if (desc->precision == FMD_PREC_W16A16) node_out_kernel<2, true, true><<<node_grid, 256, 0, s>>>(oa);
+      else if (sp) node_out_kernel<2, true, false><<<node_grid, 256, 0, s>>>(oa);
+      else node_out_kernel<2, false, false><<<node_grid, 256, 0, s>>>(oa);
     }
     ev_end();
     FMD_CHECK_LAUNCH();

@@ -21,6 +21,7 @@ from ._ffi import call, ptr, stream
 MAX_BEADS = 283
 # fmd_schnet_desc.precision (include/flashmd_hip.h): both are fp32-grade (2e-7 per contraction)
 PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, the fast default
+              "w16a16": 1,     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
               "f32_mfma": 2}   # FMD_PREC_F32_MFMA: exact fp32 MFMA kernels
 
 

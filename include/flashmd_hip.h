@@ -154,10 +154,12 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
  *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as
  *   fp16 hi + lo/2048 and a.b = hi.hi + (hi.lo + lo.hi)/2048 on v_mfma_f32_32x32x16_f16 with fp32
  *   accumulation -- relative error 2e-7, the same as fp32 MFMA, at 3/16 of its MFMA cycles) or
- *   FMD_PREC_F32_MFMA (exact fp32 products); FMD_PREC_W16A16 is reserved (returns FMD_EINVAL).
+ *   FMD_PREC_F32_MFMA (exact fp32 products); FMD_PREC_W16A16 = the reference's W16A16 mode
+ *   (models/gptq.py:92-130,266-306): filter and output networks with fp16 operands (weights =
+ *   Linear.weight.half(), activations rounded to fp16 where they are stored), fp32 accumulation.
  * ------------------------------------------------------------------------------------------- */
 #define FMD_PREC_F32 0        /* fp32 results: fp16 hi/lo split operands on the fp16 MFMA, fp32 accumulate */
-#define FMD_PREC_W16A16 1     /* reserved */
+#define FMD_PREC_W16A16 1     /* filter and output networks: fp16 operands and stored activations, fp32 accumulate */
 #define FMD_PREC_F32_MFMA 2   /* fp32 results: exact fp32 products on v_mfma_f32_32x32x2_f32 */
 
 typedef struct fmd_schnet_desc {
