@@ -5,13 +5,15 @@ Replaces, for qualifying models, what the reference does per timestep in SchNet.
 GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model
 qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
 <= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
-tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights, and no
-molecule larger than 283 beads (its aggregate must fit the 160 KB LDS).  Anything else returns
-None here and GradientsOut uses the operator path.
+tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights (or the
+W16A16 twins of models/gptq.py on both the filter and the output networks), and no molecule larger
+than 283 beads (its aggregate must fit the 160 KB LDS).  Anything else returns None here and
+GradientsOut uses the operator path.
 """
 from __future__ import annotations
 
 import ctypes
+from typing import Optional
 
 import torch
 
@@ -29,10 +31,39 @@ def _linears(mlp):
     return [m for m in mlp.layers if isinstance(m, torch.nn.Linear)]
 
 
+def _filter_weights(fn):
+    """(f0_w [128,R], f0_b [128], f1_w [128,128]) in nn.Linear layout and whether the module is the W16A16
+    twin (reference models/gptq.py:92-130, weights stored transposed in fp16)."""
+    from .gptq import GPTQW16A16FilterNetwork
+
+    if isinstance(fn, GPTQW16A16FilterNetwork):
+        return fn.weight0.t().float(), fn.bias0.float(), fn.weight1.t().float(), True
+    if not hasattr(fn, "layers"):
+        raise ValueError("fused engine: filter network must be an MLP or its W16A16 twin")
+    fl = _linears(fn)
+    if len(fl) != 2 or fl[1].bias is not None or fl[0].bias is None:
+        raise ValueError("fused engine: filter network must be Linear(R,128)+tanh+Linear(128,128,no bias)")
+    return fl[0].weight, fl[0].bias, fl[1].weight, False
+
+
+def _output_weights(on):
+    """[(w [out,in], b | None), ...] and whether the module is the W16A16 twin (models/gptq.py:266-306)."""
+    from .gptq import GPTQW16A16OutputNetwork
+
+    if isinstance(on, GPTQW16A16OutputNetwork):
+        return [(on.weight0.t().float(), on.bias0.float()), (on.weight1.t().float(), on.bias1.float()),
+                (on.weight2.t().float(), None)], True
+    if not hasattr(on, "layers"):
+        raise ValueError("fused engine: output network must be an MLP or its W16A16 twin")
+    return [(m.weight, m.bias) for m in _linears(on)], False
+
+
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0, precision: str = "f32"):
+    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None):
+        """``precision``: "f32" (default), "f32_mfma" or "w16a16"; a model whose filter and output networks
+        were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself."""
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -47,24 +78,33 @@ class FusedSchNetEngine:
             if not isinstance(cut, CosineCutoff) or cut.cutoff_lower != 0 \
                     or cut.cutoff_upper != rbf.cutoff.cutoff_upper:
                 raise ValueError("fused engine: CFConv cutoff must equal the basis cutoff")
-            if not isinstance(blk.activation, torch.nn.Tanh) or not hasattr(blk.conv.filter_network, "layers"):
-                raise ValueError("fused engine: tanh activation and an fp32 MLP filter network required")
-            fl = _linears(blk.conv.filter_network)
-            if len(fl) != 2 or fl[0].out_features != 128 or fl[1].out_features != 128 or fl[1].bias is not None:
+            if not isinstance(blk.activation, torch.nn.Tanh):
+                raise ValueError("fused engine: tanh activation required")
+        filt = [_filter_weights(blk.conv.filter_network) for blk in blocks]
+        for f0_w, f0_b, f1_w, _ in filt:
+            if tuple(f0_w.shape) != (128, rbf.num_rbf) or tuple(f1_w.shape) != (128, 128):
                 raise ValueError("fused engine: filter network must be Linear(R,128)+tanh+Linear(128,128,no bias)")
-        if hidden != 128 or not hasattr(model.output_network, "layers"):
-            raise ValueError("fused engine: hidden = filters = 128 and an fp32 MLP output network required")
-        outs = _linears(model.output_network)
-        if len(outs) not in (2, 3) or outs[-1].out_features != 1 or outs[-1].bias is not None \
-                or any(o.out_features > 128 for o in outs):
+        if hidden != 128:
+            raise ValueError("fused engine: hidden = filters = 128 required")
+        outs, out_half = _output_weights(model.output_network)
+        if len(outs) not in (2, 3) or outs[-1][0].shape[0] != 1 or outs[-1][1] is not None \
+                or any(w_.shape[0] > 128 for w_, _ in outs) or outs[0][0].shape[1] != 128:
             raise ValueError("fused engine: output MLP must have 2-3 linears, widths <= 128, last -> 1 without bias")
+        halves = [q for *_, q in filt] + [out_half]
+        if any(halves):
+            if not all(halves):
+                raise ValueError("fused engine: W16A16 needs the filter AND output networks swapped")
+            if precision not in (None, "w16a16"):
+                raise ValueError("fused engine: the model carries W16A16 networks; precision must be 'w16a16'")
+            precision = "w16a16"
+        precision = precision or "f32"
 
         self.device = model.embedding_layer.weight.device
         self.cutoff = float(rbf.cutoff.cutoff_upper)
         d = _ffi.SchnetDesc()
         d.hidden, d.num_rbf, d.num_blocks, d.num_out = 128, rbf.num_rbf, len(blocks), len(outs)
         for k in range(4):
-            d.out_width[k] = outs[k].out_features if k < len(outs) else 0
+            d.out_width[k] = outs[k][0].shape[0] if k < len(outs) else 0
         d.embedding_size = model.embedding_layer.num_embeddings
         if precision not in PRECISIONS:
             raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
@@ -82,17 +122,16 @@ class FusedSchNetEngine:
 
         bw = (_ffi.SchnetBlockWeights * len(blocks))()
         for l, blk in enumerate(blocks):
-            fl = _linears(blk.conv.filter_network)
             bw[l].lin1_w = host(blk.conv.lin1.weight)
-            bw[l].f0_w, bw[l].f0_b, bw[l].f1_w = host(fl[0].weight), host(fl[0].bias), host(fl[1].weight)
+            bw[l].f0_w, bw[l].f0_b, bw[l].f1_w = host(filt[l][0]), host(filt[l][1]), host(filt[l][2])
             bw[l].lin2_w, bw[l].lin2_b = host(blk.conv.lin2.weight), host(blk.conv.lin2.bias)
             bw[l].lin_w, bw[l].lin_b = host(blk.lin.weight), host(blk.lin.bias)
         w = _ffi.SchnetWeights()
         w.embedding = host(model.embedding_layer.weight)
         w.blocks = ctypes.cast(bw, ctypes.POINTER(_ffi.SchnetBlockWeights))
-        for k, o in enumerate(outs):
-            w.out_w[k] = host(o.weight)
-            w.out_b[k] = host(o.bias) if o.bias is not None else None
+        for k, (ow, ob) in enumerate(outs):
+            w.out_w[k] = host(ow)
+            w.out_b[k] = host(ob) if ob is not None else None
         centers = host(rbf.offset)
         nbytes = _ffi.lib().fmd_schnet_pack_bytes(ctypes.byref(d))
         if nbytes <= 0:

@@ -147,7 +147,7 @@ def test_fused_engine_exact_fp32_mfma_kernels(params, golden_dir):
     rf = float((out["f32"][1] - out["f32_mfma"][1]).norm() / out["f32_mfma"][1].norm())
     assert rf < 1e-5
     with pytest.raises(ValueError):
-        engine.FusedSchNetEngine(model, precision="w16a16")
+        engine.FusedSchNetEngine(model, precision="bf16")
 
 
 def test_fused_engine_other_hyperparameters():
@@ -222,3 +222,7 @@ def test_fused_engine_w16a16(params, golden_dir, case):
     assert rf32 < 5e-3
     e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
     assert torch.equal(f, f2) and torch.equal(e, e2)
+    # the reference's route to this mode: apply_gptq_w16a16_to_model(model), then GradientsOut picks the
+    # W16A16 engine by itself and gives the same numbers as the explicit precision
+    e3, f3 = _run(S, params, pos, types, ptr, engine=True, w16a16=True)
+    assert torch.equal(e3, e) and torch.equal(f3, f)
