@@ -1,0 +1,169 @@
+"""Classical prior terms (row N2): host mirror of the reference's prior classes and their condensed form.
+
+``HarmonicBonds`` / ``HarmonicAngles`` / ``Repulsion`` / ``Dihedral`` keep the reference's static
+``compute`` / ``compute_features`` (reference prior/harmonic.py:116-123,221-225,258-262,
+prior/repulsion.py:112-122, prior/fourier_series.py:154-192; features
+geometry/internal_coordinates.py:72-223) as plain torch ops -- the --disable_optim / CPU path.
+``StaticPriors`` is the condensed form the simulation uses (reference simulation/specialize_prior.py:76-207):
+per-term parameter arrays, evaluated with energy and forces in one HIP kernel per kind
+(``fmd_prior_energy_forces``); there is no CPU fallback for it.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Tuple
+
+import torch
+
+from . import _ffi
+from ._ffi import call, ptr, stream
+
+KIND = {"bonds": 0, "angles": 1, "repulsion": 2, "dihedrals": 3}
+ORDER = {"bonds": 2, "angles": 3, "repulsion": 2, "dihedrals": 4}
+
+
+def compute_distances(pos, mapping):
+    return (pos[mapping[1]] - pos[mapping[0]]).norm(p=2, dim=1)
+
+
+def compute_angles_cos(pos, mapping):
+    dr1, dr2 = pos[mapping[0]] - pos[mapping[1]], pos[mapping[2]] - pos[mapping[1]]
+    return (dr1 * dr2).sum(dim=1) / (dr1.norm(p=2, dim=1) * dr2.norm(p=2, dim=1))
+
+
+def compute_torsions(pos, mapping):
+    nrm = torch.nn.functional.normalize
+    dr1 = nrm(pos[mapping[1]] - pos[mapping[0]], dim=1)
+    dr2 = nrm(pos[mapping[2]] - pos[mapping[1]], dim=1)
+    dr3 = nrm(pos[mapping[3]] - pos[mapping[2]], dim=1)
+    n1, n2 = torch.cross(dr1, dr2, dim=1), torch.cross(dr2, dr3, dim=1)
+    m1 = torch.cross(n1, dr2, dim=1)
+    return torch.atan2(-(m1 * n2).sum(-1), (n1 * n2).sum(-1))
+
+
+class HarmonicBonds:
+    name, _order = "bonds", 2
+    compute_features = staticmethod(compute_distances)
+
+    @staticmethod
+    def compute(x, x0, k, V0=0):
+        return k * (x - x0) ** 2 + V0
+
+
+class HarmonicAngles(HarmonicBonds):
+    name, _order = "angles", 3
+    compute_features = staticmethod(compute_angles_cos)
+
+
+class Repulsion:
+    name, _order = "repulsion", 2
+    compute_features = staticmethod(compute_distances)
+
+    @staticmethod
+    def compute(x, sigma):
+        rr = (sigma / x) * (sigma / x)
+        return rr * rr * rr
+
+
+class Dihedral:
+    name, _order = "dihedrals", 4
+    compute_features = staticmethod(compute_torsions)
+
+    @staticmethod
+    def compute(theta, v_0, k1s, k2s):
+        n_degs = torch.arange(1, k1s.shape[1] + 1, dtype=theta.dtype, device=theta.device)
+        angles = theta.view(-1, 1) * n_degs.view(1, -1)
+        return (k1s * torch.sin(angles) + k2s * torch.cos(angles)).sum(dim=1) + v_0.view(-1)
+
+
+def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
+    """per-term parameters [P, M] from per-type tables (what data2parameters does in the reference)."""
+    idx = tuple(types[mapping[i]] for i in range(mapping.shape[0]))
+    if kind in ("bonds", "angles"):
+        return torch.stack([tables["k"][idx], tables["x_0"][idx]])
+    if kind == "repulsion":
+        return tables["sigma"][idx].unsqueeze(0)
+    n = tables["k1s"].shape[0]
+    return torch.cat([tables["v_0"][idx].unsqueeze(0)] + [tables["k1s"][i][idx].unsqueeze(0) for i in range(n)]
+                     + [tables["k2s"][i][idx].unsqueeze(0) for i in range(n)])
+
+
+class StaticPriors:
+    """All prior terms of a collated batch, condensed: for each kind ``mapping`` [order, M] (int64, global bead
+    indices, molecule-major), ``params`` [P, M] (fp32) and ``term_ptr`` [B+1]."""
+
+    def __init__(self, terms: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], max_beads: int):
+        self.terms, self.max_beads = terms, int(max_beads)
+        self.status = None
+
+    @classmethod
+    def from_tables(cls, spec: Dict[str, Tuple[Dict[str, torch.Tensor], torch.Tensor]], types, mol_ptr):
+        """spec: kind -> (per-type parameter tables, mapping [order, M]); types [N], mol_ptr [B+1] on the CPU."""
+        n_mol = mol_ptr.numel() - 1
+        mol_of_bead = torch.repeat_interleave(torch.arange(n_mol), mol_ptr[1:] - mol_ptr[:-1])
+        terms = {}
+        for kind, (tables, mapping) in spec.items():
+            assert kind in KIND and mapping.shape[0] == ORDER[kind] and mapping.dtype == torch.int64
+            mol = mol_of_bead[mapping[0]]
+            assert bool((mol[1:] >= mol[:-1]).all()), "terms must be molecule-major (collated batch order)"
+            term_ptr = torch.zeros(n_mol + 1, dtype=torch.int64)
+            term_ptr[1:] = torch.cumsum(torch.bincount(mol, minlength=n_mol), 0)
+            params = _lookup(kind, tables, types, mapping).to(torch.float32)
+            terms[kind] = (mapping.contiguous(), params.contiguous(), term_ptr)
+        return cls(terms, int((mol_ptr[1:] - mol_ptr[:-1]).max()))
+
+    def to(self, device):
+        self.terms = {k: tuple(t.to(device) for t in v) for k, v in self.terms.items()}
+        self.status = torch.zeros(4, dtype=torch.int32, device=device)
+        return self
+
+    def add_energy_forces(self, pos, mol_ptr, energy, forces):
+        """energy[B] += U_prior per molecule, forces[N,3] += -dU/dpos (in place, current stream)."""
+        _ffi.require_gpu(pos, mol_ptr, energy, forces)
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and forces.is_contiguous()
+        n_mol = mol_ptr.numel() - 1
+        for kind, (mapping, params, term_ptr) in self.terms.items():
+            call("fmd_prior_energy_forces", ptr(pos), ptr(mol_ptr), n_mol, self.max_beads, KIND[kind], ptr(mapping),
+                 ptr(params), params.shape[0], ptr(term_ptr), mapping.shape[1], ptr(energy), ptr(forces),
+                 ptr(self.status), stream())
+        return energy, forces
+
+    def energy_forces(self, pos, mol_ptr):
+        energy = torch.zeros(mol_ptr.numel() - 1, dtype=torch.float32, device=pos.device)
+        forces = torch.zeros_like(pos)
+        return self.add_energy_forces(pos, mol_ptr, energy, forces)
+
+    def energy_torch(self, pos, mol_ptr):
+        """The same energies as plain torch ops (differentiable; --disable_optim / CPU path)."""
+        n_mol = mol_ptr.numel() - 1
+        mol_of_bead = torch.repeat_interleave(torch.arange(n_mol, device=pos.device), mol_ptr[1:] - mol_ptr[:-1])
+        energy = torch.zeros(n_mol, dtype=pos.dtype, device=pos.device)
+        for kind, (mapping, params, _) in self.terms.items():
+            p = params.to(pos.dtype)
+            if kind == "bonds":
+                e = HarmonicBonds.compute(compute_distances(pos, mapping), p[1], p[0])
+            elif kind == "angles":
+                e = HarmonicAngles.compute(compute_angles_cos(pos, mapping), p[1], p[0])
+            elif kind == "repulsion":
+                e = Repulsion.compute(compute_distances(pos, mapping), p[0])
+            else:
+                n = (p.shape[0] - 1) // 2
+                e = Dihedral.compute(compute_torsions(pos, mapping), p[0], p[1:1 + n].t(), p[1 + n:].t())
+            energy = energy.index_add(0, mol_of_bead[mapping[0]], e)
+        return energy
+
+
+def sum_out(force_fns):
+    """force_fn(pos) -> (energy[B], forces[N,3]) summing several models, the role of the reference's SumOut
+    (models/gradients.py:71-152).  ``force_fns``: first a callable returning fresh (energy, forces) -- e.g. the
+    fused SchNet engine -- then objects with ``add_energy_forces(pos, mol_ptr, energy, forces)`` such as
+    StaticPriors, given as (obj, mol_ptr) pairs."""
+    first, rest = force_fns[0], force_fns[1:]
+
+    def fn(pos):
+        energy, forces = first(pos)
+        for obj, mol_ptr in rest:
+            obj.add_energy_forces(pos, mol_ptr, energy, forces)
+        return energy, forces
+
+    return fn

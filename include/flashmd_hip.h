@@ -254,6 +254,24 @@ int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* m
                       const uint8_t* accept, const float* beta_mol, int64_t n_pairs, int64_t n_atoms,
                       void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row N2: classical prior terms in the condensed ("Static") form of simulation/specialize_prior.py:76-207.
+ *   kind 0 bonds      (prior/harmonic.py:91-123,200-225)   U = k (d - x0)^2            params rows: k, x0
+ *   kind 1 angles     (prior/harmonic.py:228-262)          U = k (cos(theta) - x0)^2   params rows: k, x0
+ *   kind 2 repulsion  (prior/repulsion.py:80-122)          U = (sigma / d)^6           params rows: sigma
+ *   kind 3 dihedrals  (prior/fourier_series.py:97-192)     U = v0 + sum_n k1_n sin(n phi) + k2_n cos(n phi)
+ *                                                          params rows: v0, k1_1..k1_n, k2_1..k2_n
+ *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4), molecule-major; term_ptr [n_mol+1] i64 the
+ *   term range of each molecule; params [n_params][n_terms] f32.  ADDS the per-molecule energies to energy[n_mol]
+ *   and -dU/dpos to forces[N,3] (so it can follow fmd_schnet_energy_forces on the same buffers, which is what
+ *   the reference's SumOut does, models/gradients.py:71-152).  Fixed summation order.  status[3] |= 1 when a
+ *   term references a bead outside its molecule (that term's indices are clamped).
+ * ------------------------------------------------------------------------------------------- */
+int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr, int64_t n_mol, int64_t max_beads_per_mol,
+                            int kind, const int64_t* mapping, const float* params, int n_params,
+                            const int64_t* term_ptr, int64_t n_terms, float* energy, float* forces,
+                            int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

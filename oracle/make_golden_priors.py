@@ -1,0 +1,74 @@
+"""Generate tests/golden/case_priors.npz with the REFERENCE's own prior classes (build container only):
+``HarmonicBonds``, ``HarmonicAngles``, ``Repulsion``, ``Dihedral`` from /root/reference/src/flashmd/prior,
+evaluated in fp64 on synthetic chains; forces by autograd of the summed energies, as ``GradientsOut`` does.
+The fixture holds inputs (positions, types, mappings, per-type parameter tables) and the reference's outputs.
+
+    python oracle/make_golden_priors.py
+"""
+import os
+import sys
+import types as pytypes
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "flash-molecular-dynamics_amd"))
+from oracle import make_golden as mg  # noqa: E402  (stand-ins for nvtx / torch_geometric / torch_cluster)
+
+mg._install_standins()
+sys.path.insert(0, "/root/reference/src")
+from flashmd.prior.fourier_series import Dihedral  # noqa: E402
+from flashmd.prior.harmonic import HarmonicAngles, HarmonicBonds  # noqa: E402
+from flashmd.prior.repulsion import Repulsion  # noqa: E402
+
+from flashmd_amd import synthetic  # noqa: E402  (input generator only: no product math)
+
+
+def main():
+    torch.manual_seed(5)
+    n_mol, A, T, n_degs = 3, 41, 5, 3
+    pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
+    topo = synthetic.chain_topology(n_mol, A)
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    stats = {
+        "bonds": {(a, b): {"k": 2 + 3 * r(1)[0], "x_0": 3.6 + 0.4 * r(1)[0]} for a in range(T) for b in range(T)},
+        "angles": {(a, b, c): {"k": 1 + 4 * r(1)[0], "x_0": -0.6 + 1.2 * r(1)[0]}
+                   for a in range(T) for b in range(T) for c in range(T)},
+        "repulsion": {(a, b): {"sigma": 3.0 + 1.5 * r(1)[0]} for a in range(T) for b in range(T)},
+        "dihedrals": {(a, b, c, d): {"v_0": r(1)[0], "k1s": {f"k1_{n}": r(1)[0] - 0.5 for n in range(1, n_degs + 1)},
+                                     "k2s": {f"k2_{n}": r(1)[0] - 0.5 for n in range(1, n_degs + 1)}}
+                      for a in range(T) for b in range(T) for c in range(T) for d in range(T)},
+    }
+    models = {"bonds": HarmonicBonds(stats["bonds"]), "angles": HarmonicAngles(stats["angles"]),
+              "repulsion": Repulsion(stats["repulsion"]), "dihedrals": Dihedral(stats["dihedrals"], n_degs=n_degs)}
+    mol_of_bead = torch.arange(n_mol).repeat_interleave(A)
+    data = pytypes.SimpleNamespace(pos=pos.double().requires_grad_(True), atom_types=types, ptr=ptr, out={},
+                                   neighbor_list={k: {"index_mapping": topo[k], "mapping_batch": mol_of_bead[topo[k][0]]}
+                                                  for k in topo})
+    out = {"pos": pos.numpy(), "types": types.numpy(), "ptr": ptr.numpy(), "n_degs": np.int64(n_degs)}
+    total = 0
+    for k, m in models.items():
+        m = m.double()
+        data = m(data)
+        e = data.out[m.name]["energy"]
+        (gr,) = torch.autograd.grad(e.sum(), data.pos, retain_graph=True)
+        out[f"{k}_mapping"] = topo[k].numpy()
+        out[f"{k}_energy_ref64"] = e.detach().numpy()
+        out[f"{k}_forces_ref64"] = (-gr).numpy()
+        total = total + e
+        for name, buf in m.named_buffers():
+            out[f"{k}_table_{name}"] = buf.numpy()
+    (gr,) = torch.autograd.grad(total.sum(), data.pos)
+    out["total_energy_ref64"] = total.detach().numpy()
+    out["total_forces_ref64"] = (-gr).numpy()
+    path = os.path.join(ROOT, "tests", "golden", "case_priors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""Row N2 (classical prior terms).  CPU: the oracle restatement against the reference's own outputs
+(tests/golden/case_priors.npz, written by oracle/make_golden_priors.py from the reference's prior classes).
+GPU: the HIP path (fmd_prior_energy_forces) against the oracle and the same vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prior_oracle as po
+
+KINDS = ("bonds", "angles", "repulsion", "dihedrals")
+
+
+def _load(golden_dir):
+    z = np.load(os.path.join(golden_dir, "case_priors.npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
+    tables = {k: {n[len(k) + 7:]: torch.from_numpy(z[n]) for n in z.files if n.startswith(k + "_table_")} for k in KINDS}
+    maps = {k: torch.from_numpy(z[k + "_mapping"]) for k in KINDS}
+    return z, pos, types, ptr, tables, maps
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_prior_oracle_matches_reference_vectors(golden_dir):
+    z, pos, types, ptr, tables, maps = _load(golden_dir)
+    n_mol = ptr.numel() - 1
+    mol_of_bead = torch.repeat_interleave(torch.arange(n_mol), ptr[1:] - ptr[:-1])
+    terms = []
+    for k in KINDS:
+        prm = po.lookup(k, tables[k], types, maps[k])
+        e, f = po.prior_energy_forces(pos.double(), [(k, maps[k], prm)], mol_of_bead, n_mol)
+        assert _rel(e, z[k + "_energy_ref64"]) < 1e-12 and _rel(f, z[k + "_forces_ref64"]) < 1e-12, k
+        terms.append((k, maps[k], prm))
+    e, f = po.prior_energy_forces(pos.double(), terms, mol_of_bead, n_mol)
+    assert _rel(e, z["total_energy_ref64"]) < 1e-12 and _rel(f, z["total_forces_ref64"]) < 1e-12
+
+
+def test_prior_host_mirror_torch_path_matches_reference_vectors(golden_dir):
+    """the plain-torch branch of the host mirror (what runs with --disable_optim / on the CPU)"""
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir)
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in KINDS}, types, ptr)
+    x = pos.double().requires_grad_(True)
+    e = sp.energy_torch(x, ptr)
+    (g,) = torch.autograd.grad(e.sum(), x)
+    assert _rel(e.detach(), z["total_energy_ref64"]) < 1e-6 and _rel(-g, z["total_forces_ref64"]) < 1e-6
+    with pytest.raises(RuntimeError):  # the HIP form has no CPU fallback
+        sp.energy_forces(pos, ptr)
+
+
+@pytest.mark.gpu
+def test_prior_hip_vs_reference_vectors(golden_dir):
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir)
+    dev = "cuda:0"
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in KINDS}, types, ptr).to(dev)
+    e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    re, rf = _rel(e.cpu(), z["total_energy_ref64"]), _rel(f.cpu(), z["total_forces_ref64"])
+    print(f"priors (HIP, fp32) vs reference fp64: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-5 and rf < 1e-5
+    e2, f2 = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    assert torch.equal(e, e2) and torch.equal(f, f2)  # fixed summation order
+    for k in KINDS:  # each kind alone
+        one = prior.StaticPriors.from_tables({k: (tables[k], maps[k])}, types, ptr).to(dev)
+        ek, fk = one.energy_forces(pos.to(dev), ptr.to(dev))
+        assert _rel(ek.cpu(), z[k + "_energy_ref64"]) < 1e-5 and _rel(fk.cpu(), z[k + "_forces_ref64"]) < 2e-5, k
+
+
+@pytest.mark.gpu
+def test_prior_hip_1enh_sized_batch_vs_oracle():
+    """269-bead chains x 16 molecules (all four kinds, ~36k terms): HIP vs the fp64 oracle; empty term lists and
+    molecules without terms are accepted."""
+    from flashmd_amd import prior, synthetic
+
+    dev = "cuda:0"
+    n_mol, A, T = 16, 269, 5
+    pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
+    topo = synthetic.chain_topology(n_mol, A)
+    g = torch.Generator().manual_seed(3)
+    tables = {"bonds": {"k": 2 + torch.rand(T, T, generator=g), "x_0": 3.6 + 0.4 * torch.rand(T, T, generator=g)},
+              "angles": {"k": 1 + torch.rand(T, T, T, generator=g), "x_0": torch.rand(T, T, T, generator=g) - 0.5},
+              "repulsion": {"sigma": 3 + torch.rand(T, T, generator=g)},
+              "dihedrals": {"v_0": torch.rand(T, T, T, T, generator=g), "k1s": torch.rand(2, T, T, T, T, generator=g) - 0.5,
+                            "k2s": torch.rand(2, T, T, T, T, generator=g) - 0.5}}
+    mol_of_bead = torch.arange(n_mol).repeat_interleave(A)
+    terms = [(k, topo[k], po.lookup(k, tables[k], types, topo[k])) for k in KINDS]
+    e_o, f_o = po.prior_energy_forces(pos.double(), [(k, m, p.double()) for k, m, p in terms], mol_of_bead, n_mol)
+    sp = prior.StaticPriors.from_tables({k: (tables[k], topo[k]) for k in KINDS}, types, ptr).to(dev)
+    e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    assert _rel(e.cpu(), e_o) < 1e-5 and _rel(f.cpu(), f_o) < 1e-5
+    # bonds only in the first molecule: the others get zero
+    first = topo["bonds"][:, : A - 1]
+    sp1 = prior.StaticPriors.from_tables({"bonds": (tables["bonds"], first)}, types, ptr).to(dev)
+    e1, f1 = sp1.energy_forces(pos.to(dev), ptr.to(dev))
+    assert float(e1[1:].abs().max()) == 0.0 and float(f1[A:].abs().max()) == 0.0 and float(e1[0]) > 0
+    empty = prior.StaticPriors.from_tables({"bonds": (tables["bonds"], first[:, :0])}, types, ptr).to(dev)
+    e0, f0 = empty.energy_forces(pos.to(dev), ptr.to(dev))
+    assert float(e0.abs().max()) == 0.0 and float(f0.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_schnet_plus_priors_nve(golden_dir):
+    """SumOut analogue: fused SchNet engine + condensed priors as one force field; NVE total energy is conserved
+    (the prior forces are the gradient of the prior energies)."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, prior, simulate, synthetic
+    from oracle import schnet_oracle as so
+
+    dev = "cuda:0"
+    params = so.params_from_npz(os.path.join(golden_dir, "weights_L3_R50.npz"))
+    n_mol, A, T = 4, 120, 5
+    pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
+    topo = synthetic.chain_topology(n_mol, A)
+    tables = {"bonds": {"k": torch.full((T, T), 20.0), "x_0": torch.full((T, T), 3.8)},
+              "angles": {"k": torch.full((T, T, T), 5.0), "x_0": torch.full((T, T, T), -0.3)},
+              "repulsion": {"sigma": torch.full((T, T), 3.5)},
+              "dihedrals": {"v_0": torch.zeros(T, T, T, T), "k1s": 0.3 * torch.ones(2, T, T, T, T),
+                            "k2s": -0.2 * torch.ones(2, T, T, T, T)}}
+    sp = prior.StaticPriors.from_tables({k: (tables[k], topo[k]) for k in KINDS}, types, ptr).to(dev)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(dev))
+    P, Tt, Q = pos.to(dev), (types + 1).to(dev), ptr.to(dev)
+    ff = prior.sum_out([lambda x: eng.energy_forces(x, Tt, Q, A), (sp, Q)])
+    masses = torch.full((P.shape[0],), 12.0, device=dev)
+    sim = simulate.NVESimulation(ff, P, masses, torch.full((n_mol,), 1.67, device=dev), A, dt=0.002)
+    tot = []
+    for _ in range(200):
+        sim.timestep()
+        tot.append((sim.energy + sim.kinetic_energy()).double().cpu())
+    tot = torch.stack(tot)
+    ke = float(sim.kinetic_energy().double().mean())
+    drift = float(((tot.max(0).values - tot.min(0).values) / ke).max())
+    print(f"SchNet + priors NVE: (max-min of E_tot)/KE = {drift:.2e}")
+    assert drift < 2e-2
+    assert int(sp.status[3]) == 0
