@@ -90,7 +90,8 @@ def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
 
 class StaticPriors:
     """All prior terms of a collated batch, condensed: for each kind ``mapping`` [order, M] (int64, global bead
-    indices, molecule-major), ``params`` [P, M] (fp32) and ``term_ptr`` [B+1]."""
+    indices), ``params`` [P, M] (fp32) and the by-bead CSR of the fixed topology (``bead_ptr`` [N+1] int64,
+    ``entries`` [order*M] int32 = term << 2 | slot) the gather kernel walks."""
 
     def __init__(self, terms: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], max_beads: int):
         self.terms, self.max_beads = terms, int(max_beads)
@@ -99,21 +100,33 @@ class StaticPriors:
     @classmethod
     def from_tables(cls, spec: Dict[str, Tuple[Dict[str, torch.Tensor], torch.Tensor]], types, mol_ptr):
         """spec: kind -> (per-type parameter tables, mapping [order, M]); types [N], mol_ptr [B+1] on the CPU."""
-        n_mol = mol_ptr.numel() - 1
-        mol_of_bead = torch.repeat_interleave(torch.arange(n_mol), mol_ptr[1:] - mol_ptr[:-1])
+        n_beads = int(mol_ptr[-1])
         terms = {}
         for kind, (tables, mapping) in spec.items():
             assert kind in KIND and mapping.shape[0] == ORDER[kind] and mapping.dtype == torch.int64
-            mol = mol_of_bead[mapping[0]]
-            assert bool((mol[1:] >= mol[:-1]).all()), "terms must be molecule-major (collated batch order)"
-            term_ptr = torch.zeros(n_mol + 1, dtype=torch.int64)
-            term_ptr[1:] = torch.cumsum(torch.bincount(mol, minlength=n_mol), 0)
+            order, n_terms = mapping.shape
+            assert n_terms < (1 << 29)
             params = _lookup(kind, tables, types, mapping).to(torch.float32)
-            terms[kind] = (mapping.contiguous(), params.contiguous(), term_ptr)
+            # CSR by bead: entries (term << 2 | slot) sorted by (bead, term, slot)
+            ent = (torch.arange(n_terms).view(1, -1) * 4 + torch.arange(order).view(-1, 1)).flatten()
+            bead = mapping.flatten()
+            perm = torch.argsort(bead * (4 * max(n_terms, 1)) + ent)
+            bead_ptr = torch.zeros(n_beads + 1, dtype=torch.int64)
+            bead_ptr[1:] = torch.cumsum(torch.bincount(bead, minlength=n_beads), 0)
+            ents = ent[perm]
+            pair = None
+            if order == 2:  # partner-list form of the same CSR (used for long pair lists)
+                t, slot = ents >> 2, ents & 3
+                mol_start = mol_ptr[torch.bucketize(mapping[0][t], mol_ptr[1:], right=True)]
+                other = mapping[1 - slot, t] - mol_start
+                word = (other | ((slot == 0).to(torch.int64) << 31)).to(torch.int64)
+                pair = (word.to(torch.uint32) if hasattr(torch, "uint32") else word, params[:, t].contiguous())
+            terms[kind] = (mapping.contiguous(), params.contiguous(), bead_ptr, ents.to(torch.int32).contiguous(), pair)
         return cls(terms, int((mol_ptr[1:] - mol_ptr[:-1]).max()))
 
     def to(self, device):
-        self.terms = {k: tuple(t.to(device) for t in v) for k, v in self.terms.items()}
+        mv = lambda t: None if t is None else (tuple(u.to(device) for u in t) if isinstance(t, tuple) else t.to(device))  # noqa: E731
+        self.terms = {k: tuple(mv(t) for t in v) for k, v in self.terms.items()}
         self.status = torch.zeros(4, dtype=torch.int32, device=device)
         return self
 
@@ -122,10 +135,16 @@ class StaticPriors:
         _ffi.require_gpu(pos, mol_ptr, energy, forces)
         assert pos.dtype == torch.float32 and pos.is_contiguous() and forces.is_contiguous()
         n_mol = mol_ptr.numel() - 1
-        for kind, (mapping, params, term_ptr) in self.terms.items():
+        for kind, (mapping, params, bead_ptr, entries, pair) in self.terms.items():
+            # partner-list form for long pair lists (> 16 entries per bead on average)
+            if pair is not None and entries.numel() > 16 * pos.shape[0]:
+                call("fmd_prior_pairs_energy_forces", ptr(pos), ptr(mol_ptr), n_mol, self.max_beads, KIND[kind],
+                     ptr(bead_ptr), ptr(pair[0]), ptr(pair[1]), entries.numel(), ptr(energy), ptr(forces),
+                     ptr(self.status), stream())
+                continue
             call("fmd_prior_energy_forces", ptr(pos), ptr(mol_ptr), n_mol, self.max_beads, KIND[kind], ptr(mapping),
-                 ptr(params), params.shape[0], ptr(term_ptr), mapping.shape[1], ptr(energy), ptr(forces),
-                 ptr(self.status), stream())
+                 ptr(params), params.shape[0], ptr(bead_ptr), ptr(entries), mapping.shape[1], ptr(energy),
+                 ptr(forces), ptr(self.status), stream())
         return energy, forces
 
     def energy_forces(self, pos, mol_ptr):
@@ -138,7 +157,7 @@ class StaticPriors:
         n_mol = mol_ptr.numel() - 1
         mol_of_bead = torch.repeat_interleave(torch.arange(n_mol, device=pos.device), mol_ptr[1:] - mol_ptr[:-1])
         energy = torch.zeros(n_mol, dtype=pos.dtype, device=pos.device)
-        for kind, (mapping, params, _) in self.terms.items():
+        for kind, (mapping, params, *_) in self.terms.items():
             p = params.to(pos.dtype)
             if kind == "bonds":
                 e = HarmonicBonds.compute(compute_distances(pos, mapping), p[1], p[0])

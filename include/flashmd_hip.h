@@ -261,16 +261,27 @@ int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* m
  *   kind 2 repulsion  (prior/repulsion.py:80-122)          U = (sigma / d)^6           params rows: sigma
  *   kind 3 dihedrals  (prior/fourier_series.py:97-192)     U = v0 + sum_n k1_n sin(n phi) + k2_n cos(n phi)
  *                                                          params rows: v0, k1_1..k1_n, k2_1..k2_n
- *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4), molecule-major; term_ptr [n_mol+1] i64 the
- *   term range of each molecule; params [n_params][n_terms] f32.  ADDS the per-molecule energies to energy[n_mol]
+ *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4); params [n_params][n_terms] f32;
+ *   bead_ptr [N+1] i64 and entries [order * n_terms] i32 = the CSR of the fixed topology by bead: entry =
+ *   term << 2 | slot, the entries of bead b are bead_ptr[b]..bead_ptr[b+1] in ascending (term, slot) order
+ *   (built once per topology by the caller; n_terms < 2^29).  ADDS the per-molecule energies to energy[n_mol]
  *   and -dU/dpos to forces[N,3] (so it can follow fmd_schnet_energy_forces on the same buffers, which is what
- *   the reference's SumOut does, models/gradients.py:71-152).  Fixed summation order.  status[3] |= 1 when a
- *   term references a bead outside its molecule (that term's indices are clamped).
+ *   the reference's SumOut does, models/gradients.py:71-152).  Gather form, no atomics, fixed summation order.
+ *   status[3] |= 1 when a term references a bead outside its molecule (that term's indices are clamped).
  * ------------------------------------------------------------------------------------------- */
 int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr, int64_t n_mol, int64_t max_beads_per_mol,
                             int kind, const int64_t* mapping, const float* params, int n_params,
-                            const int64_t* term_ptr, int64_t n_terms, float* energy, float* forces,
-                            int32_t* status, void* stream);
+                            const int64_t* bead_ptr, const int32_t* entries, int64_t n_terms, float* energy,
+                            float* forces, int32_t* status, void* stream);
+
+/* Pair kinds (0 bonds, 2 repulsion) in the partner-list form, for long pair lists: the by-bead CSR holds
+ * (partner, parameters) records instead of term references -- partner [n_entries] u32 = index of the other bead
+ * inside the molecule, bit 31 set on the entry that owns the term's energy; pair_params [n_params][n_entries]
+ * f32 (k, x0 | sigma) -- 4 + 4 P bytes per entry.  Same results and conventions as fmd_prior_energy_forces. */
+int fmd_prior_pairs_energy_forces(const float* pos, const int64_t* mol_ptr, int64_t n_mol,
+                                  int64_t max_beads_per_mol, int kind, const int64_t* bead_ptr,
+                                  const uint32_t* partner, const float* pair_params, int64_t n_entries,
+                                  float* energy, float* forces, int32_t* status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -77,7 +77,9 @@ elif mode == "pt":
     v_exp = torch.where(mask, allv[peer] * math.sqrt(betas[rank] / betas[peer]), allv[rank])
     ok = torch.equal(sim.x, x_exp) and torch.allclose(sim.v, v_exp)
     a_, t_ = ex.acceptance()
-    print("PT_OK", int(ok), int(acc.sum()), int(a_[0]), int(t_[0]))
+    # one write per rank: the two ranks share a pipe and print() of several arguments can interleave
+    sys.stdout.write(f"PT_OK {int(ok)} {int(acc.sum())} {int(a_[0])} {int(t_[0])}\n")
+    sys.stdout.flush()
     ex(sim)                        # attempt 1: odd pairs -> nobody has a partner with 2 ranks
     assert ex.partner(False) is None
 dist.barrier()
@@ -122,8 +124,10 @@ def test_replica_sharding_two_ranks_matches_single_process():
 
 def test_parallel_tempering_exchange_two_ranks():
     out = _run("pt")
-    lines = [l for l in out.splitlines() if l.startswith("PT_OK")]
-    assert len(lines) == 2
-    for l in lines:
-        ok, n_acc, acc0, att0 = (int(v) for v in l.split()[1:])
+    import re
+
+    recs = re.findall(r"PT_OK (\d+) (\d+) (\d+) (\d+)", out)
+    assert len(recs) == 2, out[-500:]
+    for rec in recs:
+        ok, n_acc, acc0, att0 = (int(v) for v in rec)
         assert ok == 1 and acc0 == n_acc and att0 == 2

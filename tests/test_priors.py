@@ -81,7 +81,7 @@ def test_prior_hip_1enh_sized_batch_vs_oracle():
     dev = "cuda:0"
     n_mol, A, T = 16, 269, 5
     pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
-    topo = synthetic.chain_topology(n_mol, A)
+    topo = synthetic.chain_topology(n_mol, A, repulsion_stride=1)  # 35k pairs per chain: the partner-list path
     g = torch.Generator().manual_seed(3)
     tables = {"bonds": {"k": 2 + torch.rand(T, T, generator=g), "x_0": 3.6 + 0.4 * torch.rand(T, T, generator=g)},
               "angles": {"k": 1 + torch.rand(T, T, T, generator=g), "x_0": torch.rand(T, T, T, generator=g) - 0.5},
