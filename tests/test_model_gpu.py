@@ -226,3 +226,26 @@ def test_fused_engine_w16a16(params, golden_dir, case):
     # W16A16 engine by itself and gives the same numbers as the explicit precision
     e3, f3 = _run(S, params, pos, types, ptr, engine=True, w16a16=True)
     assert torch.equal(e3, e) and torch.equal(f3, f)
+
+
+@pytest.mark.parametrize("beads", [283, 300])
+def test_molecule_size_limits(params, beads):
+    """283 beads: the largest molecule whose aggregate fits the engine's LDS (the backward pair kernel then runs in
+    its per-wave Gaussian form: the shared fragment region no longer fits).  300 beads: GradientsOut declines the
+    engine and the operator path answers; the engine itself refuses loudly."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(2, beads, 5.0)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    e, f = _run(S, params, pos, types, ptr, engine=True)
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    print(f"{beads} beads: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    if beads > engine.MAX_BEADS:
+        with pytest.raises(RuntimeError):
+            eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    else:
+        e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+        assert torch.equal(e2, e) and torch.equal(f2, f)
