@@ -104,9 +104,10 @@ class LangevinSimulation:
         self.energy, self.f = self.force_fn(self.x)
         self.v = v + 0.5 * dt * self.f / m
 
-    def simulate(self, n_timesteps: int, subroutine=None, interval: int = 0):
+    def simulate(self, n_timesteps: int, subroutine=None, interval: int = 0, writer=None):
         """Runs the loop and returns timestep*mol/s measured over the second half
-        (reference simulation/base.py:564-571,638-642,762-768)."""
+        (reference simulation/base.py:564-571,638-642,762-768).  ``writer``: a TrajectoryWriter that
+        receives the state every ``writer.save_interval`` steps (reference :620-636)."""
         import time
 
         half = n_timesteps // 2
@@ -117,10 +118,151 @@ class LangevinSimulation:
                 sync()
                 t0 = time.perf_counter()
             self.timestep()
+            if writer is not None and (t + 1) % writer.save_interval == 0:
+                writer.save(self, t)
             if subroutine is not None and interval and (t + 1) % interval == 0:
                 subroutine(self)
         sync()
-        return (n_timesteps - half) * self.n_sims / (time.perf_counter() - t0)
+        rate = (n_timesteps - half) * self.n_sims / (time.perf_counter() - t0)
+        if writer is not None:
+            writer.close()
+        return rate
+
+    def kinetic_energy(self):
+        """per molecule, 0.5 sum m v^2 (reference simulation/langevin.py:266-271)"""
+        ke = 0.5 * self.masses * (self.v * self.v).sum(-1)
+        return ke.view(self.n_sims, self.n_atoms).sum(-1)
+
+    def load_checkpoint(self, path: str):
+        """Resume positions and velocities from a ``{filename}_checkpoint_XXXX.pt`` written by TrajectoryWriter
+        (or by the reference: same keys, simulation/base.py:1357-1418); forces are re-evaluated.  Returns the
+        chunk index the run continues from."""
+        ck = torch.load(path, weights_only=True)
+        self.x = ck["pos"].to(self.x.device, self.x.dtype).contiguous()
+        self.v = ck["velocities"].to(self.v.device, self.v.dtype).contiguous()
+        self.energy, self.f = self.force_fn(self.x)
+        return int(ck["current_timestep"])
+
+
+class TrajectoryWriter:
+    """Row N3: the reference's on-disk trajectory layout (simulation/base.py:1294-1453, langevin.py:236-291):
+    every ``save_interval`` steps a frame is kept, every ``export_interval`` steps a chunk is written as
+
+      {filename}_coords_XXXX.npy          [n_sims, frames, n_atoms, 3]
+      {filename}_forces_XXXX.npy          [n_sims, frames, n_atoms, 3]   (save_forces)
+      {filename}_potential_XXXX.npy       [n_sims, frames]               (save_energies)
+      {filename}_kineticenergy_XXXX.npy   [n_sims, frames]               (save_energies)
+      {filename}_checkpoint_XXXX.pt       {"pos", "velocities", "current_timestep", "export_interval",
+                                           "save_interval", "log_interval"}   (create_checkpoints)
+
+    Frames are staged in device memory ([frames, n_sims, n_atoms, 3] per quantity) and leave the GPU once per
+    chunk: one device-to-host copy on a side stream into pinned memory, written by a worker thread, so the
+    timestep loop never waits for the disk.  The divergence check of the reference (position spread > 1000x the
+    initial one, or NaN) is evaluated on the device per saved frame and read at export time."""
+
+    def __init__(self, filename: str, sim, save_interval: int, export_interval: int, save_forces: bool = False,
+                 save_energies: bool = False, create_checkpoints: bool = False, log_interval: int = 0):
+        assert export_interval % save_interval == 0 and export_interval >= save_interval
+        self.filename, self.save_interval, self.export_interval = filename, save_interval, export_interval
+        self.save_forces, self.save_energies, self.create_checkpoints = save_forces, save_energies, create_checkpoints
+        self.log_interval = log_interval
+        self.frames = export_interval // save_interval
+        dev, n_sims, n_atoms = sim.x.device, sim.n_sims, sim.n_atoms
+        self.coords = torch.zeros(self.frames, n_sims, n_atoms, 3, device=dev)
+        self.forces = torch.zeros_like(self.coords) if save_forces else None
+        self.potential = torch.zeros(self.frames, n_sims, device=dev) if save_energies else None
+        self.kinetic = torch.zeros(self.frames, n_sims, device=dev) if save_energies else None
+        self.initial_spread = sim.x.view(n_sims, -1).std(dim=1).max()
+        self.diverged = torch.zeros((), dtype=torch.bool, device=dev)
+        self.index = 0            # chunk counter (the XXXX of the file names)
+        self.count = 0            # frames staged in the current chunk
+        self.files = []
+        self._stream = torch.cuda.Stream(device=dev) if sim.x.is_cuda else None
+        self._worker = None
+
+    def save(self, sim, t: int):
+        k = self.count
+        x = sim.x.view(sim.n_sims, sim.n_atoms, 3)
+        spread = x.reshape(sim.n_sims, -1).std(dim=1)
+        self.diverged |= (spread.max() > 1e3 * self.initial_spread) | torch.isnan(spread).any()
+        self.coords[k] = x
+        if self.save_forces:
+            self.forces[k] = sim.f.view(sim.n_sims, sim.n_atoms, 3)
+        if self.save_energies:
+            self.potential[k] = sim.energy
+            self.kinetic[k] = sim.kinetic_energy()
+        self.count += 1
+        if self.count == self.frames:
+            self._export(sim, t)
+
+    def _export(self, sim, t: int):
+        import threading
+
+        import numpy as np
+
+        self._join()
+        key = f"{self.index:04d}"
+        out = {"coords": self.coords}
+        if self.save_forces:
+            out["forces"] = self.forces
+        if self.save_energies:
+            out["potential"], out["kineticenergy"] = self.potential, self.kinetic
+        ck = None
+        if self.create_checkpoints:
+            ck = {"pos": sim.x, "velocities": sim.v}
+        host, event = {}, None
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                for name, tns in out.items():
+                    host[name] = torch.empty(tns.transpose(0, 1).shape, dtype=tns.dtype, pin_memory=True)
+                    host[name].copy_(tns.transpose(0, 1), non_blocking=True)  # [n_sims, frames, ...]
+                if ck is not None:
+                    ck = {n_: v_.to("cpu", non_blocking=True) for n_, v_ in ck.items()}
+                flag = self.diverged.to("cpu", non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(self._stream)
+            # the staging buffers are rewritten by the next chunk: that must wait for the copies
+            torch.cuda.current_stream().wait_stream(self._stream)
+        else:
+            host = {name: tns.transpose(0, 1).contiguous().clone() for name, tns in out.items()}
+            ck = None if ck is None else {n_: v_.clone() for n_, v_ in ck.items()}
+            flag = self.diverged.clone()
+        index = self.index
+
+        def work():
+            if event is not None:
+                event.synchronize()
+            if bool(flag):
+                self._error = RuntimeError(f"Simulation of trajectory blew up before #timestep={t}")
+                return
+            for name, arr in host.items():
+                path = f"{self.filename}_{name}_{key}.npy"
+                np.save(path, arr.numpy())
+                self.files.append(path)
+            if ck is not None:
+                ck.update(current_timestep=index + 1, export_interval=self.export_interval,
+                          save_interval=self.save_interval, log_interval=self.log_interval)
+                path = f"{self.filename}_checkpoint_{key}.pt"
+                torch.save(ck, path)
+                self.files.append(path)
+
+        self._error = None
+        self._worker = threading.Thread(target=work)
+        self._worker.start()
+        self.index += 1
+        self.count = 0
+
+    def _join(self):
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+            if self._error is not None:
+                raise self._error
+
+    def close(self):
+        """Wait for the pending chunk (frames of an incomplete chunk are dropped, as in the reference)."""
+        self._join()
 
 
 class NVESimulation(LangevinSimulation):
@@ -138,11 +280,6 @@ class NVESimulation(LangevinSimulation):
         self.x = self.x + dt * v
         self.energy, self.f = self.force_fn(self.x)
         self.v = v + 0.5 * dt * self.f / m
-
-    def kinetic_energy(self):
-        """per molecule, 0.5 sum m v^2"""
-        ke = 0.5 * self.masses * (self.v * self.v).sum(-1)
-        return ke.view(self.n_sims, self.n_atoms).sum(-1)
 
 
 def pt_pairs(n_betas: int, even: bool):

@@ -121,3 +121,49 @@ def test_shard_range_partitions_molecules():
         assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_trajectory_writer_layout_and_checkpoint_resume(tmp_path):
+    """Row N3: file names, array layouts and checkpoint keys of the reference (simulation/base.py:1366-1418,
+    langevin.py:273-291), and a resume from the checkpoint, on the PyTorch path with a harmonic toy force."""
+    import numpy as np
+    import torch
+
+    from flashmd_amd import simulate
+
+    n_sims, n_atoms = 3, 5
+    g = torch.Generator().manual_seed(1)
+    pos = torch.randn(n_sims * n_atoms, 3, generator=g)
+    masses = torch.full((n_sims * n_atoms,), 12.0)
+    beta = torch.full((n_sims,), 1.67)
+
+    def ff(x):  # U = 0.5 |x|^2 per molecule
+        return 0.5 * (x * x).sum(-1).view(n_sims, n_atoms).sum(-1), -x
+
+    sim = simulate.LangevinSimulation(ff, pos, masses, beta, n_atoms, dt=0.004, use_hip=False)
+    base = str(tmp_path / "traj")
+    wr = simulate.TrajectoryWriter(base, sim, save_interval=2, export_interval=10, save_forces=True,
+                                   save_energies=True, create_checkpoints=True)
+    frames = []
+
+    def spy(s):
+        frames.append((s.x.clone(), s.f.clone(), s.energy.clone(), s.kinetic_energy().clone(), s.v.clone()))
+
+    sim.simulate(20, subroutine=spy, interval=2, writer=wr)
+    for chunk in (0, 1):
+        c = np.load(f"{base}_coords_{chunk:04d}.npy")
+        f = np.load(f"{base}_forces_{chunk:04d}.npy")
+        u = np.load(f"{base}_potential_{chunk:04d}.npy")
+        k = np.load(f"{base}_kineticenergy_{chunk:04d}.npy")
+        assert c.shape == (n_sims, 5, n_atoms, 3) and f.shape == c.shape and u.shape == (n_sims, 5) and k.shape == u.shape
+        for j in range(5):
+            x_, f_, u_, k_, _ = frames[chunk * 5 + j]
+            assert np.array_equal(c[:, j], x_.view(n_sims, n_atoms, 3).numpy())
+            assert np.array_equal(f[:, j], f_.view(n_sims, n_atoms, 3).numpy())
+            assert np.array_equal(u[:, j], u_.numpy()) and np.allclose(k[:, j], k_.numpy())
+    ck = torch.load(f"{base}_checkpoint_0001.pt", weights_only=True)
+    assert set(ck) == {"pos", "velocities", "current_timestep", "export_interval", "save_interval", "log_interval"}
+    assert ck["current_timestep"] == 2 and ck["export_interval"] == 10 and ck["save_interval"] == 2
+    sim2 = simulate.LangevinSimulation(ff, pos, masses, beta, n_atoms, dt=0.004, use_hip=False)
+    assert sim2.load_checkpoint(f"{base}_checkpoint_0001.pt") == 2
+    assert torch.equal(sim2.x, frames[-1][0]) and torch.equal(sim2.v, frames[-1][4])

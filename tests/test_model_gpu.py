@@ -249,3 +249,32 @@ def test_molecule_size_limits(params, beads):
     else:
         e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
         assert torch.equal(e2, e) and torch.equal(f2, f)
+
+
+def test_trajectory_writer_on_gpu(params, tmp_path):
+    """Row N3 on the device path: frames staged in HBM, one asynchronous copy per chunk on a side stream."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, simulate
+
+    pos, types, ptr = so.synth_batch(3, 37, 5.0)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    masses = torch.full((P.shape[0],), 12.0, device=DEV)
+    sim = simulate.LangevinSimulation(lambda x: eng.energy_forces(x, T, Q, 37), P, masses,
+                                      torch.full((3,), 1.67, device=DEV), 37)
+    base = str(tmp_path / "gpu")
+    wr = simulate.TrajectoryWriter(base, sim, save_interval=1, export_interval=4, save_forces=True, save_energies=True,
+                                   create_checkpoints=True)
+    frames = []
+    sim.simulate(8, subroutine=lambda s: frames.append((s.x.cpu().clone(), s.f.cpu().clone(), s.energy.cpu().clone())),
+                 interval=1, writer=wr)
+    for chunk in (0, 1):
+        c, f = np.load(f"{base}_coords_{chunk:04d}.npy"), np.load(f"{base}_forces_{chunk:04d}.npy")
+        u = np.load(f"{base}_potential_{chunk:04d}.npy")
+        assert c.shape == (3, 4, 37, 3) and u.shape == (3, 4)
+        for j in range(4):
+            x_, f_, u_ = frames[chunk * 4 + j]
+            assert np.array_equal(c[:, j], x_.view(3, 37, 3).numpy()) and np.array_equal(f[:, j], f_.view(3, 37, 3).numpy())
+            assert np.array_equal(u[:, j], u_.numpy())
+    ck = torch.load(f"{base}_checkpoint_0001.pt", weights_only=True)
+    assert torch.equal(ck["pos"], frames[-1][0])
