@@ -278,3 +278,57 @@ def test_trajectory_writer_on_gpu(params, tmp_path):
             assert np.array_equal(u[:, j], u_.numpy())
     ck = torch.load(f"{base}_checkpoint_0001.pt", weights_only=True)
     assert torch.equal(ck["pos"], frames[-1][0])
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
+def test_full_size_batch_properties(params, precision):
+    """BASELINE config size (128 molecules x 269 beads, 1.9M directed edges), where the fp64 oracle is too slow to be
+    the checker: size-independent properties of the force field instead.
+      * a molecule's result does not depend on where it sits in the batch (bitwise: permute the molecules);
+      * replicas of one molecule give bit-identical results, equal to that molecule evaluated alone;
+      * energies are invariant under a rigid rotation + translation, forces rotate with the frame;
+      * internal forces: zero net force and zero net torque per molecule;
+      * a subset of the molecules agrees with the fp64 oracle."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    B, A = 128, 269
+    pos, types, ptr = so.synth_batch(B, A, 5.0)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV), precision=precision)
+    T, Q = types.to(DEV), ptr.to(DEV)
+    e, f = eng.energy_forces(pos.to(DEV), T, Q, A)
+    assert int(eng.status[0]) == 0 and torch.isfinite(f).all()
+    X, Fm = pos.view(B, A, 3), f.view(B, A, 3).cpu()
+    # permutation of molecules
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0))
+    e_p, f_p = eng.energy_forces(X[perm].reshape(-1, 3).contiguous().to(DEV), T, Q, A)
+    assert torch.equal(e_p.cpu(), e.cpu()[perm]) and torch.equal(f_p.view(B, A, 3).cpu(), Fm[perm])
+    # replicas, and the molecule alone (other n_split, other workgroup)
+    rep = X[5:6].expand(B, A, 3).reshape(-1, 3).contiguous().to(DEV)
+    e_r, f_r = eng.energy_forces(rep, T, Q, A)
+    assert bool((e_r == e_r[0]).all()) and bool((f_r.view(B, A, 3) == f_r.view(B, A, 3)[0]).all())
+    e_1, f_1 = eng.energy_forces(X[5].contiguous().to(DEV), T[:A], Q[:2], A)
+    tol = 2e-3 if precision == "w16a16" else 2e-5  # another n_split regroups the partial sums
+    assert float((f_1.cpu() - Fm[5]).norm() / Fm[5].norm()) < tol
+    assert float((e_1.cpu() - e.cpu()[5]).abs() / e.cpu()[5].abs()) < tol
+    # rigid motion
+    g = torch.Generator().manual_seed(1)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g, dtype=torch.float64))
+    q = q * torch.sign(torch.linalg.det(q))
+    moved = (pos.double() @ q.T + torch.tensor([3.0, -2.0, 1.5], dtype=torch.float64)).float()
+    e_m, f_m = eng.energy_forces(moved.to(DEV), T, Q, A)
+    tol = 3e-3 if precision == "w16a16" else 3e-5
+    assert float((e_m - e).abs().max() / e.abs().max()) < tol
+    assert float((f_m.cpu().double() - f.cpu().double() @ q.T).norm() / f.cpu().double().norm()) < tol
+    # Newton's third law
+    scale = Fm.norm(dim=2).mean()
+    net = Fm.double().sum(1).norm(dim=1).max() / scale
+    torque = torch.linalg.cross(X.double() - X.double().mean(1, keepdim=True), Fm.double()).sum(1).norm(dim=1).max() / scale
+    print(f"{precision}: net force {float(net):.2e}, net torque {float(torque):.2e} (units of the mean |F|)")
+    assert float(net) < (5e-2 if precision == "w16a16" else 1e-3) and float(torque) < (1.0 if precision == "w16a16" else 3e-2)
+    # a subset against the oracle
+    sub = slice(40 * A, 42 * A)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sub].double(), types[:2 * A], ptr[:3],
+                                       w16a16=False)
+    re, rf = _relerr(e[40:42], f[sub], e_o.numpy(), f_o.numpy())
+    assert rf < (3e-3 if precision == "w16a16" else 1e-4) and re < (3e-3 if precision == "w16a16" else 1e-4)
