@@ -1764,6 +1764,18 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
 // ---------------------------------------------------------------------------------------------
 // node kernels (32-row tiles, chained 128x128 slices through two LDS tile buffers)
 // ---------------------------------------------------------------------------------------------
+// this lane's 16 elements (its column, the tile's rows) of a [N,128] array: issued at the top of a tile so
+// the loads fly under the GEMM chain instead of adding a memory latency to every stage
+__device__ __forceinline__ f32x16 prefetch_col(const float* __restrict__ src, int64_t row0, int64_t n_rows,
+                                               int col, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t row = row0 + tile_row(r, h);
+    v[r] = row < n_rows ? src[row * F + col] : 0.f;
+  }
+  return v;
+}
 struct NodeFwdArgs {
   const int64_t* types;
   const float* emb;
@@ -1802,6 +1814,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
         tile_store4<SPLIT>(bufA, r, c, v);
       }
     } else {
+      const f32x16 x_old = prefetch_col(a.x, row0, a.n_nodes, col, h);
       rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
       __syncthreads();
       f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);  // conv = agg lin2^T + b2
@@ -1821,7 +1834,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
         const int64_t row = row0 + tile_row(r, h);
         float xn = 0.f;
         if (row < a.n_nodes) {
-          xn = a.x[row * F + col] + (acc[r] + b3);
+          xn = x_old[r] + (acc[r] + b3);
           a.x[row * F + col] = xn;
         }
         acc[r] = xn;
@@ -1865,6 +1878,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32;
+    const f32x16 x_old = prefetch_col(a.x, row0, a.n_nodes, col, h);
     rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
     __syncthreads();
     f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);
@@ -1882,7 +1896,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
-      acc[r] = row < a.n_nodes ? a.x[row * F + col] + (acc[r] + b3) : 0.f;
+      acc[r] = row < a.n_nodes ? x_old[r] + (acc[r] + b3) : 0.f;
     }
     if (HOUT) tile_store_half(bufA, acc, w, lane);
     else tile_store<SPLIT>(bufA, acc, w, lane);
@@ -1960,6 +1974,9 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32;
+    const f32x16 t_pre = prefetch_col(a.t, row0, a.n_nodes, col, h);
+    f32x16 gx_pre;
+    if (HAS_SLABS) gx_pre = prefetch_col(a.gx, row0, a.n_nodes, col, h);
     f32x16 acc;
     if (HAS_SLABS) {  // gx += (sum of gx1 partials) lin1
       rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
@@ -1970,7 +1987,7 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
         const int64_t row = row0 + tile_row(r, h);
         float v = 0.f;
         if (row < a.n_nodes) {
-          v = a.gx[row * F + col] + acc[r];
+          v = gx_pre[r] + acc[r];
           a.gx[row * F + col] = v;
         }
         acc[r] = v;
@@ -1984,7 +2001,7 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
-      const float tv = row < a.n_nodes ? a.t[row * F + col] : 0.f;
+      const float tv = t_pre[r];
       acc[r] *= 1.0f - tv * tv;
     }
     tile_store<SPLIT>(bufA, acc, w, lane);
