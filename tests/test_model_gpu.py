@@ -332,3 +332,26 @@ def test_full_size_batch_properties(params, precision):
                                        w16a16=False)
     re, rf = _relerr(e[40:42], f[sub], e_o.numpy(), f_o.numpy())
     assert rf < (3e-3 if precision == "w16a16" else 1e-4) and re < (3e-3 if precision == "w16a16" else 1e-4)
+
+
+def test_fused_engine_degenerate_molecules(params):
+    """Molecules without any pair inside the cutoff (a single bead; two beads 50 apart), a 2-bead molecule, and a
+    normal one in the same ragged batch; and the empty batch."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(4)
+    mols = [torch.zeros(1, 3), torch.tensor([[0.0, 0, 0], [50.0, 0, 0]]), torch.tensor([[0.0, 0, 0], [3.0, 0, 0]]),
+            so.synth_batch(1, 40, 5.0)[0], 2.0 * torch.randn(9, 3, generator=g)]
+    pos = torch.cat(mols)
+    ptr = torch.tensor([0] + list(np.cumsum([m.shape[0] for m in mols])), dtype=torch.int64)
+    types = torch.randint(1, 20, (pos.shape[0],), generator=g)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+    assert float(f[:3].abs().max()) == 0.0          # no neighbour inside the cutoff: no force
+    assert float((e.cpu().double() - e_o).abs().max() / e_o.abs().max()) < 1e-5
+    assert float((f.cpu().double() - f_o).norm() / f_o.norm()) < 1e-4
+    e0, f0 = eng.energy_forces(pos[:0].to(DEV), types[:0].to(DEV), ptr[:1].to(DEV), 1)
+    assert e0.numel() == 0 and f0.numel() == 0
