@@ -2376,8 +2376,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const float* pk = reinterpret_cast<const float*>(packed_dev);
 
   int kidx = 0;  // kernel index in launch order (fmd_schnet_kernel_name)
-  auto ev_begin = [&]() { if (ev) (void)hipEventRecord(ev[2 * kidx], s); };
-  auto ev_end = [&]() { if (ev) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
+  // a NULL slot skips that record: a caller may time a single kernel without paying for 2 records per launch
+  auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
+  auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
   const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
   ev_begin();
