@@ -18,6 +18,7 @@
 //    the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice GEMMs), so the only
 //    per-pair quantity that reaches HBM is one float (dE/dd) per pair.
 #include <string.h>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 #include <stdlib.h>
@@ -2391,9 +2392,20 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int ks0 = (desc->num_rbf + 1) / 2;
   // [tile region 4352 floats][red 128][centres 64][bias 128][aggregate rows]
   const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + max_beads_per_mol * F) * sizeof(float);
-  hipError_t he = ks0 <= 16 ? set_edge_attrs<16>(lds_edge)
-                  : ks0 <= 25 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
-  if (he != hipSuccess) return FMD_ELAUNCH;
+  // the dynamic-LDS ceilings of the pair kernels only need raising when a larger molecule shows up
+  // (per device: the attribute belongs to the device's copy of the kernel)
+  {
+    static std::atomic<size_t> lds_set[3][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FMD_ELAUNCH;
+    const int cls = ks0 <= 16 ? 0 : (ks0 <= 25 ? 1 : 2);
+    if (lds_set[cls][dev].load(std::memory_order_relaxed) < lds_edge) {
+      hipError_t he = cls == 0 ? set_edge_attrs<16>(lds_edge)
+                      : cls == 1 ? set_edge_attrs<25>(lds_edge) : set_edge_attrs<32>(lds_edge);
+      if (he != hipSuccess) return FMD_ELAUNCH;
+      lds_set[cls][dev].store(lds_edge, std::memory_order_relaxed);
+    }
+  }
 
   const bool sp = desc->precision != FMD_PREC_F32_MFMA;
   const int64_t n_tiles = (n_nodes + 31) / 32;
