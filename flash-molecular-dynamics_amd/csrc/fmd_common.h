@@ -70,8 +70,18 @@ __device__ __forceinline__ float fmd_tanh_clamped(float x) {
   return (e - 1.0f) / (e + 1.0f);
 }
 
+// v + (v of the lane 32 away), in every lane: v_permlane32_swap (one VALU op on gfx950) instead of the LDS
+// round trip of ds_bpermute.  swap(x, y): lanes 32-63 of x <-> lanes 0-31 of y, so with x = y = v the pair
+// becomes (lower half everywhere, upper half everywhere).
+__device__ __forceinline__ float fmd_xor32_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 __device__ __forceinline__ float fmd_wave_sum(float v) {
+  v = fmd_xor32_sum(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }

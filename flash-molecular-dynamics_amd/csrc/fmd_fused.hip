@@ -711,7 +711,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         *reinterpret_cast<float*>(aggb + oj_c[4 * q + e]) = vj[e] + xi_c[4 * q + e] * Wq[e];
-      si += __shfl_xor(si, 32, 64);
+      si = fmd_xor32_sum(si);
       float* ci = reinterpret_cast<float*>(aggb + oi_c[4 * q]);
       *ci += si;  // both halves store the same value to the same address
     }
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             *reinterpret_cast<float*>(aggb + X.oj[4 * q + e]) = vj[e] + X.xi[q] * Wq[e];
-          si += __shfl_xor(si, 32, 64);
+          si = fmd_xor32_sum(si);
           // both halves store the same value to the same address
           *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + si;
         });
@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
                            f32x2{k_cu[r], k_cu[r + 1]};
           tot += pr[0] + pr[1];
         }
-        tot += __shfl_xor(tot, 32, 64);
+        tot = fmd_xor32_sum(tot);
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_STAMP(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               *reinterpret_cast<float*>(gx1b + X.oj[4 * q + e]) = vj[e] + X.gi[q] * Wq[e];
-            si += __shfl_xor(si, 32, 64);
+            si = fmd_xor32_sum(si);
             *reinterpret_cast<float*>(gx1b + X.oi[q]) = cval + si;
           });
         }
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           *reinterpret_cast<float*>(gx1b + oj_c[4 * q + e]) = vj[e] + gi[4 * q + e] * Wq[e];
-        si += __shfl_xor(si, 32, 64);
+        si = fmd_xor32_sum(si);
         float* ci = reinterpret_cast<float*>(gx1b + oi_c[4 * q]);
         *ci += si;
       }
@@ -1746,7 +1746,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
       g_rbf += u[r] * (1.0f - hh * hh) * azp[r];
     }
     float tot = C * g_rbf + dC * g_c;
-    tot += __shfl_xor(tot, 32, 64);
+    tot = fmd_xor32_sum(tot);
     if (h == 0) red[w * 32 + c32] = tot;
     __syncthreads();
     if (w == 0 && h == 0) {
