@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int RBF_WAVES = 4;
+constexpr int RBF_KC = 61;  // grad_rbf columns staged per pass in the backward kernel (62.5 KB of LDS)
 
 __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_fwd_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ esrc, const int64_t* __restrict__ edst,
@@ -46,7 +47,10 @@ __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
     const float* __restrict__ centers, float gamma, float rc, int64_t n_edges, int n_rbf,
     const float* __restrict__ dist, const float* __restrict__ gdist, const float* __restrict__ grbf,
     float* __restrict__ gpos) {
-  __shared__ float sd[RBF_WAVES][64], sc[RBF_WAVES][64], sdc[RBF_WAVES][64], sacc[RBF_WAVES][64];
+  // grad_rbf is [E, R] row-major: the wave's 64 x R block is read coalesced and staged in LDS ([64][R + 1]: odd
+  // stride, conflict-free), then lane e sums its own row against d(rbf)/dd.  (The first version added every
+  // element with an LDS float atomic: ~3 cycles per lane on this chip, 10x the cost of the staging.)
+  extern __shared__ float stage[];  // [RBF_WAVES][64 * (R | 1 + ...)]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t e0 = ((int64_t)blockIdx.x * RBF_WAVES + wave) * 64;
   if (e0 >= n_edges) return;
@@ -56,25 +60,32 @@ __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
     d = dist[e];
     fmd_cutoff2(d, rc, c, dc);
   }
-  sd[wave][lane] = d;
-  sc[wave][lane] = c;
-  sdc[wave][lane] = dc;
-  sacc[wave][lane] = 0.f;
+  float acc = 0.f;
   if (grbf) {
+    const int kc = min(n_rbf, RBF_KC), ld = kc | 1;  // columns per pass (one pass for R <= 61)
+    float* st = stage + (size_t)wave * 64 * ld;
     const int ne = (int)min((int64_t)64, n_edges - e0);
-    const int total = ne * n_rbf;
     const float* g = grbf + e0 * n_rbf;
-    for (int t = lane; t < total; t += 64) {
-      const int el = t / n_rbf, k = t - el * n_rbf;
-      const float diff = sd[wave][el] - centers[k];
-      const float ex = __expf(gamma * diff * diff);
-      // d rbf / d d = 2 gamma diff ex C + ex C'            (cfconv_kernels.py:1716-1719)
-      const float dr = ex * (2.0f * gamma * diff * sc[wave][el] + sdc[wave][el]);
-      atomicAdd(&sacc[wave][el], g[t] * dr);  // LDS float atomic
+    const float g2c = 2.0f * gamma * c;
+    for (int k0 = 0; k0 < n_rbf; k0 += kc) {
+      const int kn = min(kc, n_rbf - k0);
+      for (int t = lane; t < ne * kn; t += 64) {
+        const int el = t / kn, k = t - el * kn;
+        st[el * ld + k] = g[(int64_t)el * n_rbf + k0 + k];
+      }
+      // written and read by the same wave: its LDS operations complete in order
+      if (lane < ne) {
+        for (int k = 0; k < kn; ++k) {
+          const float diff = d - centers[k0 + k];
+          const float ex = __expf(gamma * diff * diff);
+          // d rbf / d d = 2 gamma diff ex C + ex C'            (cfconv_kernels.py:1716-1719)
+          acc += st[lane * ld + k] * (ex * (g2c * diff + dc));
+        }
+      }
     }
   }
   if (e < n_edges) {
-    float gd = sacc[wave][lane];
+    float gd = acc;
     if (gdist) gd += gdist[e];
     const int64_t s = esrc[e], t = edst[e];
     const float dx = pos[3 * t] - pos[3 * s], dy = pos[3 * t + 1] - pos[3 * s + 1],
@@ -117,7 +128,9 @@ extern "C" int fmd_distance_rbf_cutoff_bwd(const float* pos, const int64_t* edge
   if (n_edges == 0) return FMD_OK;
   if (!pos || !edge_src || !edge_dst || !centers || !dist) return FMD_EINVAL;
   const int64_t nblk = (n_edges + RBF_WAVES * 64 - 1) / (RBF_WAVES * 64);
-  rbf_bwd_kernel<<<(unsigned)nblk, RBF_WAVES * 64, 0, s>>>(pos, edge_src, edge_dst, centers, gamma,
+  const int kc = (int)(n_rbf < RBF_KC ? n_rbf : RBF_KC);
+  const size_t lds = grad_rbf ? (size_t)RBF_WAVES * 64 * (kc | 1) * sizeof(float) : 0;
+  rbf_bwd_kernel<<<(unsigned)nblk, RBF_WAVES * 64, lds, s>>>(pos, edge_src, edge_dst, centers, gamma,
                                                          cutoff, n_edges, (int)n_rbf, dist, grad_dist,
                                                          grad_rbf, grad_pos);
   FMD_CHECK_LAUNCH();
