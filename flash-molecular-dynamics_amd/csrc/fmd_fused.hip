@@ -32,6 +32,7 @@ constexpr int LDA = 132;          // LDS row stride (floats) of a 32 x 128 opera
 constexpr int TILE_FLOATS = 32 * LDA;
 constexpr size_t MAX_LDS_BYTES = 160 * 1024;
 constexpr int MAX_LDS_ROWS = 283; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
+constexpr int MAX_LDS_ROWS_FS = 535;  // ... in feature-split mode (64 features per workgroup, any num_rbf)
 constexpr int SLICE = 4 * 64 * 64;  // floats of one packed 128x128 operand ([wave][k-step][lane])
 constexpr int P0_FLOATS = 4 * 32 * 64;
 
@@ -574,6 +575,8 @@ struct EdgeArgs {
   const float* pc;         // C(d) per pair
   const float* pdc;        // C'(d) per pair
   float* pgd;              // dE/dd per pair (backward)
+  int64_t pgd_stride;      // FS mode: second dE/dd slab at pgd + pgd_stride
+  bool fs;                 // feature-split mode (host dispatch only)
   const int32_t* npairs;
   const int64_t* mol_ptr;
   const float* x1;         // [N,128] of this block
@@ -983,7 +986,11 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
 // fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
 // edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
 // =================================================================================================
-template <int NS0, bool STAMP, bool HALF>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
+// FS ("feature split", molecules of 284..566 beads): the aggregate of the whole molecule does not fit the LDS at 128
+// features per row, so each of the molecule's TWO workgroups keeps 64 features of it (blockIdx.x = which half),
+// walks ALL tiles, stages the full hidden tile (the producers' work is done twice per molecule) and runs two
+// consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
+template <int NS0, bool STAMP, bool HALF, bool FS>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -996,13 +1003,15 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int64_t a0 = a.mol_ptr[m];
   const int n = (int)(a.mol_ptr[m + 1] - a0);
   const int np = a.npairs[m];
-  for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int AW = FS ? 64 : F;  // aggregate row width kept in LDS
+  for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
   const float* pcut = a.pc + (int64_t)m * a.cap;
   const int ntiles = (np + 31) >> 5;
-  const int S = a.n_split;
+  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
+  const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tprev = 0;  // diagnostic build only
 #define FMD_STAMP(acc)                                         \
@@ -1013,7 +1022,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   }
   __syncthreads();
   if (STAMP) tprev = __builtin_readcyclecounter();
-  if (split < ntiles) {  // uniform over the workgroup
+  if (T0 < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0];
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h);
-      float d_n = pdist[min(split * 32, last_base) + c32], c_n = pcut[min(split * 32, last_base) + c32];
+      float d_n = pdist[min(T0 * 32, last_base) + c32], c_n = pcut[min(T0 * 32, last_base) + c32];
       f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
       auto compute = [&](int t_next) {
         const float d = d_n, C = c_n;
@@ -1068,10 +1077,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
-      compute(split + S);
+      compute(T0 + S);
       put();
       __syncthreads();  // A(first)
-      for (int t = split; t < ntiles; t += S) {
+      for (int t = T0; t < ntiles; t += S) {
         compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
         FMD_STAMP(ts0)
         __syncthreads();     // B(t)
@@ -1083,13 +1092,24 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
+      if (FS && w >= 2) {  // no feature slice for this wave in FS mode: keep the barrier protocol
+        __syncthreads();  // A(first)
+        for (int t = T0; t < ntiles; t += S) {
+          __syncthreads();  // B(t)
+          __syncthreads();  // A(t+S)
+        }
+      } else {
+      const int cw = FS ? 2 * split + w : w;  // feature slice of this wave
       f16x8 b1h[8], b1l[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
-        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
       }
-      const uint32_t col4 = (uint32_t)(32 * w + c32) * 4u;
+      const uint32_t col4 = (uint32_t)(32 * cw + c32) * 4u;
+      // byte offset inside the LDS aggregate of the row/column a global offset o = row * 512 + col4 names
+      const int lds_adj = (32 * w + c32) * 4 - (int)(col4 >> 1);
+      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
       const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
       char* aggb = reinterpret_cast<char*>(agg);
       SegRegs X;
@@ -1130,26 +1150,26 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             Wq[e] = fl[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
-            vj[e] = *reinterpret_cast<const float*>(aggb + X.oj[4 * q + e]);
+            vj[e] = *reinterpret_cast<const float*>(aggb + lo(X.oj[4 * q + e]));
             si += X.xj[4 * q + e] * Wq[e];
           }
-          const float cval = *reinterpret_cast<const float*>(aggb + X.oi[q]);
+          const float cval = *reinterpret_cast<const float*>(aggb + lo(X.oi[q]));
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            *reinterpret_cast<float*>(aggb + X.oj[4 * q + e]) = vj[e] + X.xi[q] * Wq[e];
+            *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wq[e];
           si = fmd_xor32_sum(si);
           // both halves store the same value to the same address
-          *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + si;
+          *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
         });
       };
       // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
       // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
       // between the two barriers where the producers only write LDS.
-      fetch_meta(split);
+      fetch_meta(T0);
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
       f32x16 fl_prev = zero16();
       __syncthreads();  // A(first)
-      for (int t = split; t < ntiles; t += S) {
+      for (int t = T0; t < ntiles; t += S) {
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16(), acc2 = zero16();
         {
@@ -1185,6 +1205,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         FMD_STAMP(ts3)
       }
       message(fl_prev);  // last tile
+      }
     }
   }
   if (STAMP && lane == 0) {
@@ -1194,8 +1215,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #undef FMD_STAMP
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
-  for (int i = tid * 4; i < n * F; i += 2048)
-    *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+  if (FS) {  // this half's 64 features, zeros in the other half (the node kernels add the slabs)
+    for (int i = tid * 4; i < n * 64; i += 2048) {
+      const int row = i >> 6, c = i & 63;
+      *reinterpret_cast<f32x4*>(out + row * F + 64 * split + c) = *reinterpret_cast<const f32x4*>(agg + i);
+      *reinterpret_cast<f32x4*>(out + row * F + 64 * (1 - split) + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+    for (int i = tid * 4; i < n * F; i += 2048)
+      *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+  }
 }
 
 // =================================================================================================
@@ -1212,7 +1241,9 @@ struct SegRegsB {             // consumer state of one tile (register r = 4q + e
   float xi[4], xj[16], gi[4], gj[16];
 };
 
-template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP, bool SHARE, bool HALF>
+// FS: feature-split mode for molecules of 284..566 beads, see edge_fwd_split_kernel (each of the molecule's two
+// workgroups: all tiles, 64 features of gx1, its own dE/dd slab -- the u GEMM only sees its 64 features of gW).
+template <int NS0, bool NEED_GX1, bool FIRST, bool STAMP, bool SHARE, bool HALF, bool FS>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -1233,8 +1264,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int64_t a0 = a.mol_ptr[m];
   const int n = (int)(a.mol_ptr[m + 1] - a0);
   const int np = a.npairs[m];
+  constexpr int AW = FS ? 64 : F;  // gx1 row width kept in LDS
   if (NEED_GX1)
-    for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 64) cen_l[tid] = a.centers[tid];
   if (tid < 128) b0_l[tid] = a.b0[tid];
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
@@ -1242,9 +1274,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const float* pdist = a.pd + (int64_t)m * a.cap;
   const float* pcut = a.pc + (int64_t)m * a.cap;
   const float* pdcut = a.pdc + (int64_t)m * a.cap;
-  float* pgd = a.pgd + (int64_t)m * a.cap;
+  float* pgd = a.pgd + (int64_t)m * a.cap + (FS ? split * a.pgd_stride : 0);  // FS: one dE/dd slab per half
   const int ntiles = (np + 31) >> 5;
-  const int S = a.n_split;
+  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
+  const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
   unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;  // diagnostic build only
 #define FMD_STAMP(k)                                           \
@@ -1255,7 +1288,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   }
   __syncthreads();
   if (STAMP) tprev = __builtin_readcyclecounter();
-  if (split < ntiles) {  // uniform over the workgroup
+  if (T0 < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
@@ -1268,10 +1301,12 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
         }
       }
+      constexpr int NKU = FS ? 4 : 8;          // k-steps of the u GEMM: the features of gW this workgroup holds
+      const int ku0 = FS ? 4 * split : 0;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + s) * 64 + lane];
-        if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + s) * 64 + lane];
+      for (int s = 0; s < NKU; ++s) {
+        wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + ku0 + s) * 64 + lane];
+        if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + ku0 + s) * 64 + lane];
       }
       // meta of the tile to stage next (lane = pair view)
       float d_n, c_n, dc_n, gd_n = 0.f;
@@ -1363,14 +1398,14 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) k_cu[r] = k_nx[r];
         gd_cu = gd_nx;
       };
-      fetch(split);
+      fetch(T0);
       if (SHARE) __syncthreads();  // fragments of the first tile visible
-      compute(split + S);
+      compute(T0 + S);
       if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
       rotate();
       put();
       __syncthreads();  // A(first)
-      for (int t = split; t < ntiles; t += S) {
+      for (int t = T0; t < ntiles; t += S) {
         compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
         FMD_STAMP(0)
         __syncthreads();     // B(t)
@@ -1381,13 +1416,13 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         f32x16 u1 = zero16(), u2 = zero16();
         {
           // gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
-          const _Float16* gph = hid_hi + c32 * LDH + 8 * h;
-          const _Float16* gpl = hid_lo + c32 * LDH + 8 * h;
+          const _Float16* gph = hid_hi + c32 * LDH + 8 * h + 16 * ku0;
+          const _Float16* gpl = hid_lo + c32 * LDH + 8 * h + 16 * ku0;
           f16x8 bh = *reinterpret_cast<const f16x8*>(gph), bl = *reinterpret_cast<const f16x8*>(gpl);
-          static_for<0, 8>([&](auto sc) {
+          static_for<0, NKU>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             f16x8 nh = bh, nl = bl;
-            if constexpr (s + 1 < 8) {
+            if constexpr (s + 1 < NKU) {
               nh = *reinterpret_cast<const f16x8*>(gph + 16 * (s + 1));
               nl = *reinterpret_cast<const f16x8*>(gpl + 16 * (s + 1));
             }
@@ -1421,14 +1456,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
+      const bool slice_owner = !FS || w < 2;  // FS: waves 2, 3 only share Gaussians and keep the barriers
+      const int cw = FS ? 2 * split + (w & 1) : w;
       f16x8 b1h[8], b1l[8];
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(w * 8 + s) * 64 + lane];
-        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(w * 8 + s) * 64 + lane];
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
       }
-      const int col = 32 * w + c32;
+      const int col = 32 * cw + c32;
       const uint32_t col4 = (uint32_t)col * 4u;
+      const int lds_adj = (32 * (w & 1) + c32) * 4 - (int)(col4 >> 1);
+      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
       const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
       const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F);
       char* gx1b = reinterpret_cast<char*>(gx1);
@@ -1479,17 +1518,26 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
         }
       };
-      fetch_meta(split);
+      fetch_meta(T0);
       fill();
       if (SHARE) share_fragments();
-      fetch_meta(split + S);
+      fetch_meta(T0 + S);
       if (SHARE) {
         __syncthreads();  // first tile's fragments visible
         __syncthreads();  // ... and consumed
         share_fragments();
       }
       __syncthreads();  // A(first)
-      for (int t = split; t < ntiles; t += S) {
+      for (int t = T0; t < ntiles; t += S) {
+        if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
+          fetch_meta(t + 2 * S);
+          __syncthreads();  // B(t)
+          __syncthreads();  // C(t)
+          if (SHARE) share_fragments();
+          __syncthreads();  // D(t)
+          __syncthreads();  // A(t+S)
+          continue;
+        }
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16(), acc2 = zero16();
         {
@@ -1539,15 +1587,15 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               Wq[e] = fl[4 * q + e];  // already filt * C
-              vj[e] = *reinterpret_cast<const float*>(gx1b + X.oj[4 * q + e]);
+              vj[e] = *reinterpret_cast<const float*>(gx1b + lo(X.oj[4 * q + e]));
               si += X.gj[4 * q + e] * Wq[e];
             }
-            const float cval = *reinterpret_cast<const float*>(gx1b + X.oi[q]);
+            const float cval = *reinterpret_cast<const float*>(gx1b + lo(X.oi[q]));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              *reinterpret_cast<float*>(gx1b + X.oj[4 * q + e]) = vj[e] + X.gi[q] * Wq[e];
+              *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wq[e];
             si = fmd_xor32_sum(si);
-            *reinterpret_cast<float*>(gx1b + X.oi[q]) = cval + si;
+            *reinterpret_cast<float*>(gx1b + lo(X.oi[q])) = cval + si;
           });
         }
         FMD_STAMP(0)
@@ -1582,8 +1630,16 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   if (NEED_GX1) {
     __syncthreads();
     float* out = a.slabs + split * a.slab_stride + a0 * F;
-    for (int i = tid * 4; i < n * F; i += 2048)
-      *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(gx1 + i);
+    if (FS) {  // this half's 64 features, zeros in the other half
+      for (int i = tid * 4; i < n * 64; i += 2048) {
+        const int row = i >> 6, c = i & 63;
+        *reinterpret_cast<f32x4*>(out + row * F + 64 * split + c) = *reinterpret_cast<const f32x4*>(gx1 + i);
+        *reinterpret_cast<f32x4*>(out + row * F + 64 * (1 - split) + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      for (int i = tid * 4; i < n * F; i += 2048)
+        *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(gx1 + i);
+    }
   }
 }
 
@@ -2026,6 +2082,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      const uint32_t* __restrict__ poj,
                                                      const float* __restrict__ pd,
                                                      const float* __restrict__ pgd,
+                                                     const float* __restrict__ pgd2,  // FS: second slab or null
                                                      const int32_t* __restrict__ npairs, int cap,
                                                      const float* __restrict__ e_node,
                                                      float* __restrict__ energy,
@@ -2059,7 +2116,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     }
     if (i != j) {  // pad entries carry nothing
       const float d = fmaxf(pd[(int64_t)m * cap + p], 1e-8f);
-      const float s = pgd[(int64_t)m * cap + p] / d;
+      const float gdd = pgd[(int64_t)m * cap + p] + (pgd2 ? pgd2[(int64_t)m * cap + p] : 0.f);
+      const float s = gdd / d;
       const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
       const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
       const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
@@ -2139,7 +2197,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   w.pd = (float*)take(n_mol * cap * 4);
   w.pc = (float*)take(n_mol * cap * 4);
   w.pdc = (float*)take(n_mol * cap * 4);
-  w.pgd = (float*)take(n_mol * cap * 4);
+  w.pgd = (float*)take(2 * n_mol * cap * 4);  // second slab: feature-split mode
   w.npairs = (int32_t*)take(n_mol * 4);
   w.total = p - reinterpret_cast<char*>(base);
   return w;
@@ -2172,9 +2230,12 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       else edge_fwd_ws_kernel<KS0, false><<<grid, 512, lds, s>>>(ea);
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
-      if (d->precision == FMD_PREC_W16A16) edge_fwd_split_kernel<NS0, false, true><<<grid, 512, lds, s>>>(ea);
-      else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false><<<grid, 512, lds, s>>>(ea);
-      else edge_fwd_split_kernel<NS0, false, false><<<grid, 512, lds, s>>>(ea);
+      const bool half = d->precision == FMD_PREC_W16A16;
+      if (ea.fs && half) edge_fwd_split_kernel<NS0, false, true, true><<<grid, 512, lds, s>>>(ea);
+      else if (ea.fs) edge_fwd_split_kernel<NS0, false, false, true><<<grid, 512, lds, s>>>(ea);
+      else if (half) edge_fwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(ea);
+      else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(ea);
+      else edge_fwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(ea);
     }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
@@ -2192,8 +2253,22 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       const char* mode_sh = getenv("FMD_EDGE_BWD_SHARE");  // experiments: "0" disables
       const bool share = lds_sh <= MAX_LDS_BYTES && !(mode_sh && mode_sh[0] == '0');
       const bool half = d->precision == FMD_PREC_W16A16;
-#define FMD_BWD(N_, F_, T_, S_, H_) edge_bwd_split_kernel<NS0, N_, F_, T_, S_, H_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(ea)
-      if (share && half) {
+#define FMD_BWD(N_, F_, T_, S_, H_) edge_bwd_split_kernel<NS0, N_, F_, T_, S_, H_, false><<<grid, 512, (S_) ? lds_sh : lds, s>>>(ea)
+#define FMD_BWD_FS(N_, F_, H_) edge_bwd_split_kernel<NS0, N_, F_, false, true, H_, true><<<grid, 512, lds_sh, s>>>(ea)
+      if (ea.fs) {  // feature-split mode: the fragment region always fits beside 64-wide rows
+        if (lds_sh > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
+        if (half) {
+          if (need && first) FMD_BWD_FS(true, true, true);
+          else if (need) FMD_BWD_FS(true, false, true);
+          else if (first) FMD_BWD_FS(false, true, true);
+          else FMD_BWD_FS(false, false, true);
+        } else {
+          if (need && first) FMD_BWD_FS(true, true, false);
+          else if (need) FMD_BWD_FS(true, false, false);
+          else if (first) FMD_BWD_FS(false, true, false);
+          else FMD_BWD_FS(false, false, false);
+        }
+      } else if (share && half) {
         if (need && first) FMD_BWD(true, true, false, true, true);
         else if (need) FMD_BWD(true, false, false, true, true);
         else if (first) FMD_BWD(false, true, false, true, true);
@@ -2216,6 +2291,7 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
         else FMD_BWD(false, false, false, false, false);
       }
 #undef FMD_BWD
+#undef FMD_BWD_FS
     }
   }
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
@@ -2235,15 +2311,18 @@ hipError_t set_edge_attrs(size_t lds) {
   e = hipFuncSetAttribute((const void*)edge_fwd_ws_kernel<KS0, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, true, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)edge_fwd_split_kernel<(2 * KS0 + 15) / 16, false, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  {
+    constexpr int NSF = (2 * KS0 + 15) / 16;
+    const void* fwd[] = {(const void*)edge_fwd_split_kernel<NSF, false, false, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, true, false, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, true, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, false, true>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, true, true>};
+    for (const void* f : fwd) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
+      if (e != hipSuccess) return e;
+    }
+  }
   e = hipFuncSetAttribute((const void*)edge_bwd_kernel<KS0, true, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -2257,27 +2336,35 @@ hipError_t set_edge_attrs(size_t lds) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   constexpr int NS0 = (2 * KS0 + 15) / 16;
-  const void* plain[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, false>,
-                         (const void*)edge_bwd_split_kernel<NS0, true, true, false, false, true>,
-                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, true>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, true>,
-                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, true>};
+  const void* plain[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, false, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, true, false, false, true, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, true, false, false, false, true, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, true, false, false, true, false>,
+                         (const void*)edge_bwd_split_kernel<NS0, false, false, false, false, true, false>};
   for (const void* f : plain) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  const void* shared[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, true, false>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, false, true, true, false>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, false>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, false>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, false>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, true, false, true, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, true>,
-                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, true>};
+  const void* shared[] = {(const void*)edge_bwd_split_kernel<NS0, true, true, false, true, false, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, true, true, false, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, false, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, false, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, false, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, true, false, true, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, true, false>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, true, false, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, false, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, true, false, true, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, true, false, false, true, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, true, false, true, true, true>,
+                          (const void*)edge_bwd_split_kernel<NS0, false, false, false, true, true, true>};
   for (const void* f : shared) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
     if (e != hipSuccess) return e;
@@ -2353,7 +2440,7 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
   if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0 || max_pairs_per_mol < 0) return FMD_EINVAL;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   const int split = desc->n_split > 0 ? (desc->n_split > 8 ? 8 : desc->n_split) : 8;
-  return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split).total + 256;
+  return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
 }
 
 static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
@@ -2365,13 +2452,16 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   if (n_mol == 0 || n_nodes == 0) return FMD_OK;
   if (!packed_dev || !pos || !atom_types || !mol_ptr || !energy || !forces || !workspace || !status)
     return FMD_EINVAL;
-  if (max_beads_per_mol < 1 || max_beads_per_mol > MAX_LDS_ROWS) return FMD_EUNSUPPORTED;
+  if (max_beads_per_mol < 1 || max_beads_per_mol > MAX_LDS_ROWS_FS) return FMD_EUNSUPPORTED;
+  // feature-split mode: the split kernels only (fp32-grade default and W16A16)
+  const bool fs = max_beads_per_mol > MAX_LDS_ROWS;
+  if (fs && desc->precision == FMD_PREC_F32_MFMA) return FMD_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return FMD_EINVAL;
   hipStream_t s = fmd_stream(stream);
   const int L = desc->num_blocks;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
-  const int split = resolve_split(desc, n_mol);
+  const int split = fs ? 2 : resolve_split(desc, n_mol);  // FS: the two feature halves
   const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, split);
   const PackLayout PL = pack_layout(desc);
   const float* pk = reinterpret_cast<const float*>(packed_dev);
@@ -2391,7 +2481,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
 
   const int ks0 = (desc->num_rbf + 1) / 2;
   // [tile region 4352 floats][red 128][centres 64][bias 128][aggregate rows]
-  const size_t lds_edge = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + max_beads_per_mol * F) * sizeof(float);
+  const size_t lds_edge =
+      (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + max_beads_per_mol * (fs ? 64 : F)) * sizeof(float);
   // the dynamic-LDS ceilings of the pair kernels only need raising when a larger molecule shows up
   // (per device: the attribute belongs to the device's copy of the kernel)
   {
@@ -2427,6 +2518,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.q0ch = pk + o.q0ch; ea.q0cl = pk + o.q0cl; ea.c0 = 0.5f * desc->cutoff; ea.nb = (desc->num_rbf + 7) / 8;
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
+    ea.pgd_stride = n_mol * cap; ea.fs = fs;
     ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);
     ea.stamps2 = reinterpret_cast<unsigned long long*>(g_stamp_buffer2);
     if (ks0 <= 16) return run_edges<16>(desc, fwd, l, L, ea, egrid, lds_edge, s);
@@ -2508,7 +2600,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   }
   ev_begin();
   finish_kernel<<<(unsigned)n_mol, 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
-      pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, ws.npairs, (int)cap, ws.e_node, energy, forces);
+      pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, fs ? ws.pgd + n_mol * cap : nullptr, ws.npairs, (int)cap,
+      ws.e_node, energy, forces);
   ev_end();
   FMD_CHECK_LAUNCH();
   return FMD_OK;

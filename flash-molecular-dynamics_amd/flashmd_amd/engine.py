@@ -7,8 +7,9 @@ qualifies when it has the StandardSchNet shape the kernels are built for: Gaussi
 <= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
 tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights (or the
 W16A16 twins of models/gptq.py on both the filter and the output networks), and no molecule larger
-than 283 beads (its aggregate must fit the 160 KB LDS).  Anything else returns None here and
-GradientsOut uses the operator path.
+than 535 beads (up to 283 a molecule's aggregate fits one workgroup's LDS; up to 535 the engine
+switches to its feature-split mode, two workgroups holding 64 features each).  Anything else returns
+None here and GradientsOut uses the operator path.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch
 from . import _ffi
 from ._ffi import call, ptr, stream
 
-MAX_BEADS = 283
+MAX_BEADS = 535   # 283 with the whole aggregate in one workgroup's LDS, 535 in feature-split mode
 # fmd_schnet_desc.precision (include/flashmd_hip.h): both are fp32-grade (2e-7 per contraction)
 PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, the fast default
               "w16a16": 1,     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate

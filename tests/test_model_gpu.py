@@ -228,11 +228,12 @@ def test_fused_engine_w16a16(params, golden_dir, case):
     assert torch.equal(e3, e) and torch.equal(f3, f)
 
 
-@pytest.mark.parametrize("beads", [283, 300])
+@pytest.mark.parametrize("beads", [283, 300, 400, 535, 540])
 def test_molecule_size_limits(params, beads):
-    """283 beads: the largest molecule whose aggregate fits the engine's LDS (the backward pair kernel then runs in
-    its per-wave Gaussian form: the shared fragment region no longer fits).  300 beads: GradientsOut declines the
-    engine and the operator path answers; the engine itself refuses loudly."""
+    """283 beads: the largest molecule whose aggregate fits one workgroup's LDS (the backward pair kernel then runs
+    in its per-wave Gaussian form: the shared fragment region no longer fits).  284..535 beads: the engine's
+    feature-split mode (two workgroups per molecule, 64 features of the aggregate each).  540 beads: GradientsOut
+    declines the engine and the operator path answers; the engine itself refuses loudly."""
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
