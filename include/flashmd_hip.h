@@ -202,8 +202,9 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
                                    int64_t max_pairs_per_mol);
 /* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY, [1] = max pairs seen in one molecule,
  * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
-/* max_beads_per_mol: upper bound on beads of one molecule (<= 283: the per-molecule aggregate lives
- * in LDS; larger molecules return FMD_EUNSUPPORTED and take the operator path).
+/* max_beads_per_mol: upper bound on beads of one molecule.  The per-molecule aggregate lives in LDS: up to 283
+ * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each;
+ * FMD_PREC_F32 and FMD_PREC_W16A16 only).  Larger molecules return FMD_EUNSUPPORTED and take the operator path.
  * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
  *   multiples of 8 entries; A(A-1)/2 + 8A can never overflow.
  * workspace: fmd_schnet_workspace_bytes bytes, 256-byte aligned. */
