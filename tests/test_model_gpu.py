@@ -356,3 +356,32 @@ def test_fused_engine_degenerate_molecules(params):
     assert float((f.cpu().double() - f_o).norm() / f_o.norm()) < 1e-4
     e0, f0 = eng.energy_forces(pos[:0].to(DEV), types[:0].to(DEV), ptr[:1].to(DEV), 1)
     assert e0.numel() == 0 and f0.numel() == 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
+def test_feature_split_mode_properties(params, precision):
+    """300-bead molecules (the engine's feature-split mode), both arithmetic modes: parity with the matching oracle,
+    bitwise invariance under a permutation of the molecules, zero net force per molecule, reproducibility."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    B, A = 12, 300
+    pos, types, ptr = so.synth_batch(B, A, 5.0)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV), precision=precision)
+    T, Q = types.to(DEV), ptr.to(DEV)
+    e, f = eng.energy_forces(pos.to(DEV), T, Q, A)
+    e2, f2 = eng.energy_forces(pos.to(DEV), T, Q, A)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2))
+    e_p, f_p = eng.energy_forces(pos.view(B, A, 3)[perm].reshape(-1, 3).contiguous().to(DEV), T, Q, A)
+    assert torch.equal(e_p.cpu(), e.cpu()[perm]) and torch.equal(f_p.view(B, A, 3).cpu(), f.view(B, A, 3).cpu()[perm])
+    Fm = f.view(B, A, 3).cpu().double()
+    assert float(Fm.sum(1).norm(dim=1).max() / Fm.norm(dim=2).mean()) < 1e-3
+    sub = slice(0, 2 * A)
+    w16 = precision == "w16a16"
+    p_o = params if w16 else so.params_to(params, torch.float64)
+    x_o = pos[sub] if w16 else pos[sub].double()
+    e_o, f_o = so.schnet_energy_forces(p_o, x_o, types[sub], ptr[:3], w16a16=w16)
+    re, rf = _relerr(e[:2], f[sub], e_o.numpy(), f_o.numpy())
+    print(f"feature-split {precision}: energy {re:.2e} forces {rf:.2e}")
+    assert re < (2e-3 if w16 else 1e-4) and rf < (2e-3 if w16 else 1e-4)
