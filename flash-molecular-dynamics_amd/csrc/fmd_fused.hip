@@ -348,6 +348,36 @@ __device__ __forceinline__ f32x16 gemm_rows_split(const float* lds_a, const floa
   for (int r = 0; r < 16; ++r) acc1[r] += acc2[r] * SPLIT_INV;
   return acc1;
 }
+// The same GEMM with the operand's fragments already in registers: lets a kernel that chains several GEMMs per
+// tile issue the NEXT operand's loads (L2, ~1-2 us) before it runs the current one.
+struct BFrag {
+  f16x8 h[8], l[8];
+};
+__device__ __forceinline__ void load_bfrag(BFrag& b, const float* pk, int w, int lane) {
+  asm volatile("" : "+s"(pk));  // the loads stay where they are written (not hoisted out of the tile loop)
+  const f16x8* bh = reinterpret_cast<const f16x8*>(pk) + (int64_t)w * 8 * 64 + lane;
+  const f16x8* bl = reinterpret_cast<const f16x8*>(pk + Q1_FLOATS) + (int64_t)w * 8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    b.h[s] = bh[s * 64];
+    b.l[s] = bl[s * 64];
+  }
+}
+__device__ __forceinline__ f32x16 gemm_rows_frag(const float* lds_a, const BFrag& b, int lane) {
+  f32x16 acc1 = zero16(), acc2 = zero16();
+  const uint32_t* ap = reinterpret_cast<const uint32_t*>(lds_a) + (lane & 31) * LDA + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(ap + 16 * s);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(ap + 16 * s + 4);
+    f16x8 ah, al;
+    unpack_frag(v0, v1, ah, al);
+    mfma_split(ah, al, b.h[s], b.l[s], acc1, acc2);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] += acc2[r] * SPLIT_INV;
+  return acc1;
+}
 template <bool SPLIT>
 __device__ __forceinline__ f32x16 gemm_rows(const float* lds_a, const float* __restrict__ pk, int w,
                                             int lane) {
@@ -1933,12 +1963,42 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
   const int col = 32 * w + (lane & 31);
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
+  // the 2 + 2 NUM_OUT GEMMs of a tile, in order: lin2, lin, output net forward, output net backward
+  constexpr int NOPS = 2 + 2 * NUM_OUT;
+  const float* ops[NOPS];
+  ops[0] = a.l2;
+  ops[1] = a.l3;
+#pragma unroll
+  for (int k = 0; k < NUM_OUT; ++k) {
+    ops[2 + k] = a.po[k];
+    ops[2 + NUM_OUT + k] = a.pot[NUM_OUT - 1 - k];
+  }
+  // fp32-grade form: operand fragments double-buffered in registers, the next GEMM's operand is requested (L2)
+  // before the current GEMM runs (this kernel has one wave per SIMD: the registers are there)
+  constexpr bool PIPE = SPLIT && !HOUT;
+  BFrag fb0, fb1;
+  auto gemm = [&](auto idx_c, const float* tile, bool more_tiles) -> f32x16 {
+    constexpr int idx = decltype(idx_c)::value;
+    if constexpr (PIPE) {
+      BFrag& cur = (idx & 1) ? fb1 : fb0;
+      BFrag& nxt = (idx & 1) ? fb0 : fb1;
+      if constexpr (idx + 1 < NOPS) load_bfrag(nxt, ops[idx + 1], w, lane);
+      else if (more_tiles) load_bfrag(nxt, ops[0], w, lane);  // NOPS is even: nxt is fb0 again
+      return gemm_rows_frag(tile, cur, lane);
+    } else if constexpr (HOUT && idx >= 2) {
+      return gemm_rows_half(tile, ops[idx], w, lane);
+    } else {
+      return gemm_rows_nohoist<SPLIT>(tile, ops[idx], w, lane);
+    }
+  };
+  if (PIPE && (int64_t)blockIdx.x < n_tiles) load_bfrag(fb0, ops[0], w, lane);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32;
+    const bool more = tile + gridDim.x < n_tiles;
     const f32x16 x_old = prefetch_col(a.x, row0, a.n_nodes, col, h);
     rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
     __syncthreads();
-    f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);
+    f32x16 acc = gemm(std::integral_constant<int, 0>{}, bufA, more);
     const float b2 = a.b2[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1948,7 +2008,7 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     }
     tile_store<SPLIT>(bufB, acc, w, lane);
     __syncthreads();
-    acc = gemm_rows<SPLIT>(bufB, a.l3, w, lane);
+    acc = gemm(std::integral_constant<int, 1>{}, bufB, more);
     const float b3 = a.b3[col];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1962,9 +2022,9 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     f32x16 hk[2];
     float* cur = bufA;
     float* nxt = bufB;
-#pragma unroll
-    for (int k = 0; k < NUM_OUT - 1; ++k) {
-      hk[k] = HOUT ? gemm_rows_half(cur, a.po[k], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.po[k], w, lane);
+    static_for<0, NUM_OUT - 1>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur, more);
       const float bk = a.bo[k][col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) hk[k][r] = fmd_tanh_fast(hk[k][r] + bk);
@@ -1972,9 +2032,8 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
       else tile_store<SPLIT>(nxt, hk[k], w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    const f32x16 e = HOUT ? gemm_rows_half(cur, a.po[NUM_OUT - 1], w, lane)
-                          : gemm_rows_nohoist<SPLIT>(cur, a.po[NUM_OUT - 1], w, lane);
+    });
+    const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur, more);
     if (col == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1990,17 +2049,18 @@ __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
     else tile_store<SPLIT>(nxt, g, w, lane);
     __syncthreads();
     { float* tmp = cur; cur = nxt; nxt = tmp; }
-#pragma unroll
-    for (int k = NUM_OUT - 1; k >= 1; --k) {
-      g = HOUT ? gemm_rows_half(cur, a.pot[k], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.pot[k], w, lane);
+    static_for<0, NUM_OUT - 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;   // operand pot[NUM_OUT-1-j], multiplies by 1 - hk[NUM_OUT-2-j]^2
+      constexpr int k = NUM_OUT - 1 - j;
+      g = gemm(std::integral_constant<int, 2 + NUM_OUT + j>{}, cur, more);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
       if (HOUT) tile_store_half(nxt, g, w, lane);  // f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
       else tile_store<SPLIT>(nxt, g, w, lane);
       __syncthreads();
       float* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    g = HOUT ? gemm_rows_half(cur, a.pot[0], w, lane) : gemm_rows_nohoist<SPLIT>(cur, a.pot[0], w, lane);
+    });
+    g = gemm(std::integral_constant<int, NOPS - 1>{}, cur, more);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + tile_row(r, h);
