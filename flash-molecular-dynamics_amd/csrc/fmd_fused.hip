@@ -469,13 +469,17 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
-                                                    int32_t* __restrict__ status) {
+                                                    int32_t* __restrict__ status, int max_beads) {
   // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin):
   // lanes sweep the candidates j > i 64 at a time from LDS, hits are counted / compacted with a ballot.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
-  const int n = (int)(mol_ptr[m + 1] - a0);
+  int n = (int)(mol_ptr[m + 1] - a0);
+  if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
+    if (threadIdx.x == 0) status[0] = FMD_EINVAL;
+    n = max_beads;
+  }
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
@@ -624,6 +628,7 @@ struct EdgeArgs {
   int64_t slab_stride;
   float gamma, rc;
   int cap, n_split;
+  int max_beads;           // the caller's bound on beads per molecule: what the dynamic LDS was sized for
   unsigned long long* stamps;  // diagnostic builds only (forward kernels)
   unsigned long long* stamps2; // diagnostic builds only (backward split kernel, middle block)
 };
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const int m = blockIdx.y, split = blockIdx.x;
   const int64_t a0 = a.mol_ptr[m];
-  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   for (int i = tid * 4; i < n * F; i += 1024) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   float w0[KS0], w1[64], b0r[16], cen[KS0];
@@ -812,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
   const int w = wave & 3;            // feature slice
   const int m = blockIdx.y, split = blockIdx.x;
   const int64_t a0 = a.mol_ptr[m];
-  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   for (int i = tid * 4; i < n * F; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int w = wave & 3;            // feature slice
   const int m = blockIdx.y, split = blockIdx.x;
   const int64_t a0 = a.mol_ptr[m];
-  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   constexpr int AW = FS ? 64 : F;  // aggregate row width kept in LDS
   for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1292,7 +1297,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int w = wave & 3;            // feature slice
   const int m = blockIdx.y, split = blockIdx.x;
   const int64_t a0 = a.mol_ptr[m];
-  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   constexpr int AW = FS ? 64 : F;  // gx1 row width kept in LDS
   if (NEED_GX1)
@@ -1682,7 +1687,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const int m = blockIdx.y, split = blockIdx.x;
   const int64_t a0 = a.mol_ptr[m];
-  const int n = (int)(a.mol_ptr[m + 1] - a0);
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   if (NEED_GX1)
     for (int i = tid * 4; i < n * F; i += 1024) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2146,11 +2151,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ npairs, int cap,
                                                      const float* __restrict__ e_node,
                                                      float* __restrict__ energy,
-                                                     float* __restrict__ forces) {
+                                                     float* __restrict__ forces, int max_beads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
-  const int n = (int)(mol_ptr[m + 1] - a0);
+  const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
   float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos
   __shared__ float esum[4];
   for (int i = tid; i < 12 * n; i += 256) smem[i] = 0.f;
@@ -2535,7 +2540,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
-                                                     ws.pc, ws.pdc, ws.npairs, status);
+                                                     ws.pc, ws.pdc, ws.npairs, status, (int)max_beads_per_mol);
   ev_end();
   FMD_CHECK_LAUNCH();
 
@@ -2578,7 +2583,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.q0ch = pk + o.q0ch; ea.q0cl = pk + o.q0cl; ea.c0 = 0.5f * desc->cutoff; ea.nb = (desc->num_rbf + 7) / 8;
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
-    ea.pgd_stride = n_mol * cap; ea.fs = fs;
+    ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
     ea.stamps = reinterpret_cast<unsigned long long*>(g_stamp_buffer);
     ea.stamps2 = reinterpret_cast<unsigned long long*>(g_stamp_buffer2);
     if (ks0 <= 16) return run_edges<16>(desc, fwd, l, L, ea, egrid, lds_edge, s);
@@ -2661,7 +2666,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   ev_begin();
   finish_kernel<<<(unsigned)n_mol, 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
       pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, fs ? ws.pgd + n_mol * cap : nullptr, ws.npairs, (int)cap,
-      ws.e_node, energy, forces);
+      ws.e_node, energy, forces, (int)max_beads_per_mol);
   ev_end();
   FMD_CHECK_LAUNCH();
   return FMD_OK;

@@ -200,7 +200,9 @@ int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_weights* w, co
 
 int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, int64_t n_nodes,
                                    int64_t max_pairs_per_mol);
-/* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY, [1] = max pairs seen in one molecule,
+/* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY (pair list too small) / FMD_EINVAL (a molecule has more
+ * beads than max_beads_per_mol: it was truncated to stay inside the LDS sized for that bound -- results are
+ * meaningless), [1] = max pairs seen in one molecule,
  * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
 /* max_beads_per_mol: upper bound on beads of one molecule.  The per-molecule aggregate lives in LDS: up to 283
  * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each;

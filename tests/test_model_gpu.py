@@ -385,3 +385,20 @@ def test_feature_split_mode_properties(params, precision):
     re, rf = _relerr(e[:2], f[sub], e_o.numpy(), f_o.numpy())
     print(f"feature-split {precision}: energy {re:.2e} forces {rf:.2e}")
     assert re < (2e-3 if w16 else 1e-4) and rf < (2e-3 if w16 else 1e-4)
+
+
+def test_wrong_bead_bound_is_flagged_not_faulted(params):
+    """A caller that understates max_beads_per_mol gets status[0] = FMD_EINVAL (and no out-of-bounds LDS access: the
+    kernels truncate the molecule to the bound the LDS was sized for); with the right bound the same engine works."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(2, 60, 5.0)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    eng.energy_forces(P, T, Q, 40)          # wrong: the molecules have 60 beads
+    assert int(eng.status[0]) == -1
+    e, f = eng.energy_forces(P, T, Q, 60)
+    assert int(eng.status[0]) == 0
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    assert _relerr(e, f, e_o.numpy(), f_o.numpy())[1] < 1e-4
