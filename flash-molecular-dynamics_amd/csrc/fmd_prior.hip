@@ -35,12 +35,16 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
                                                      const int64_t* __restrict__ bead_ptr,
                                                      const int32_t* __restrict__ entries, int64_t n_terms,
                                                      float* __restrict__ energy, float* __restrict__ forces,
-                                                     int32_t* __restrict__ status) {
+                                                     int32_t* __restrict__ status, int max_beads) {
   constexpr int ORDER = KIND == 0 || KIND == 2 ? 2 : (KIND == 1 ? 3 : 4);
   extern __shared__ __attribute__((aligned(16))) float sp[];  // [3n] positions of the molecule
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
-  const int n = (int)(mol_ptr[m + 1] - a0);
+  int n = (int)(mol_ptr[m + 1] - a0);
+  if (n > max_beads) {  // wrong bound from the caller: stay inside the LDS sized for it, flag it
+    if (threadIdx.x == 0) atomicOr(&status[3], 2);
+    n = max_beads;
+  }
   __shared__ float esum[16];
   for (int i = tid; i < 3 * n; i += 1024) sp[i] = pos[3 * a0 + i];
   __syncthreads();
@@ -160,11 +164,15 @@ __global__ __launch_bounds__(1024) void prior_pair_kernel(const float* __restric
                                                           const uint32_t* __restrict__ partner,
                                                           const float* __restrict__ pparams, int64_t n_entries,
                                                           float* __restrict__ energy, float* __restrict__ forces,
-                                                          int32_t* __restrict__ status) {
+                                                          int32_t* __restrict__ status, int max_beads) {
   extern __shared__ __attribute__((aligned(16))) float sp[];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
-  const int n = (int)(mol_ptr[m + 1] - a0);
+  int n = (int)(mol_ptr[m + 1] - a0);
+  if (n > max_beads) {  // wrong bound from the caller: stay inside the LDS sized for it, flag it
+    if (threadIdx.x == 0) atomicOr(&status[3], 2);
+    n = max_beads;
+  }
   __shared__ float esum[16];
   for (int i = tid; i < 3 * n; i += 1024) sp[i] = pos[3 * a0 + i];
   __syncthreads();
@@ -234,13 +242,13 @@ extern "C" int fmd_prior_pairs_energy_forces(const float* pos, const int64_t* mo
                             (int)lds) != hipSuccess)
       return FMD_ELAUNCH;
     prior_pair_kernel<0><<<(unsigned)n_mol, 1024, lds, s>>>(pos, mol_ptr, bead_ptr, partner, pair_params, n_entries,
-                                                            energy, forces, status);
+                                                            energy, forces, status, (int)max_beads_per_mol);
   } else {
     if (hipFuncSetAttribute((const void*)prior_pair_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return FMD_ELAUNCH;
     prior_pair_kernel<2><<<(unsigned)n_mol, 1024, lds, s>>>(pos, mol_ptr, bead_ptr, partner, pair_params, n_entries,
-                                                            energy, forces, status);
+                                                            energy, forces, status, (int)max_beads_per_mol);
   }
   FMD_CHECK_LAUNCH();
   return FMD_OK;
@@ -267,7 +275,8 @@ extern "C" int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr,
                             (int)lds) != hipSuccess)                                                       \
       return FMD_ELAUNCH;                                                                                  \
     prior_kernel<K, W><<<(unsigned)n_mol, 1024, lds, s>>>(pos, mol_ptr, mapping, params, n_params, bead_ptr, \
-                                                          entries, n_terms, energy, forces, status);       \
+                                                          entries, n_terms, energy, forces, status,        \
+                                                          (int)max_beads_per_mol);                        \
   }
   // bonded terms: a handful of entries per bead -> lane per bead; pair lists -> wave per bead
   if (kind == 0) FMD_PRIOR(0, false)

@@ -272,7 +272,8 @@ int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* m
  *   (built once per topology by the caller; n_terms < 2^29).  ADDS the per-molecule energies to energy[n_mol]
  *   and -dU/dpos to forces[N,3] (so it can follow fmd_schnet_energy_forces on the same buffers, which is what
  *   the reference's SumOut does, models/gradients.py:71-152).  Gather form, no atomics, fixed summation order.
- *   status[3] |= 1 when a term references a bead outside its molecule (that term's indices are clamped).
+ *   status[3] |= 1 when a term references a bead outside its molecule (that term's indices are clamped),
+ *   |= 2 when a molecule has more beads than max_beads_per_mol (it is truncated to the LDS sized for the bound).
  * ------------------------------------------------------------------------------------------- */
 int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr, int64_t n_mol, int64_t max_beads_per_mol,
                             int kind, const int64_t* mapping, const float* params, int n_params,
