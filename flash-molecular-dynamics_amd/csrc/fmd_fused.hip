@@ -602,6 +602,24 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
 // ---------------------------------------------------------------------------------------------
 // edge kernels
 // ---------------------------------------------------------------------------------------------
+// Workgroup -> (molecule, split), XCD aware.  Workgroups are dealt to the 8 XCDs round-robin in linear-id order
+// (id = blockIdx.y * gridDim.x + blockIdx.x), and every XCD has its own L2.  The S workgroups of one molecule
+// gather the same x1 / d(agg) rows, so they are given ids that are equal mod 8: ids are taken in groups of
+// 8 S = 8 molecules x S splits, id = 8 S g + 8 split + r  <->  molecule 8 g + r.  The last n_mol % 8 molecules
+// keep the plain (molecule-major) order.
+__device__ __forceinline__ void wg_to_mol_split(int& m, int& split) {
+  const int S = gridDim.x, n_mol = gridDim.y;
+  const int lid = blockIdx.y * S + blockIdx.x;
+  const int grouped = (n_mol & ~7) * S;
+  if (lid < grouped) {
+    const int g = lid / (8 * S), rem = lid - g * 8 * S;
+    split = rem >> 3;
+    m = 8 * g + (rem & 7);
+  } else {
+    m = blockIdx.y;
+    split = blockIdx.x;
+  }
+}
 struct EdgeArgs {
   const uint32_t* poi;     // centre row byte offsets (i * 512)
   const uint32_t* poj;     // neighbour row byte offsets (j * 512)
@@ -639,7 +657,8 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   float* hid = smem;                 // [32][LDA]
   float* agg = smem + TILE_FLOATS;   // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
-  const int m = blockIdx.y, split = blockIdx.x;
+  int m, split;
+  wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -815,7 +834,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
-  const int m = blockIdx.y, split = blockIdx.x;
+  int m, split;
+  wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -1034,7 +1054,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
-  const int m = blockIdx.y, split = blockIdx.x;
+  int m, split;
+  wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -1295,7 +1316,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
-  const int m = blockIdx.y, split = blockIdx.x;
+  int m, split;
+  wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -1685,7 +1707,8 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
   float* red = smem + TILE_FLOATS;         // [4][32]
   float* gx1 = smem + TILE_FLOATS + 128;   // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
-  const int m = blockIdx.y, split = blockIdx.x;
+  int m, split;
+  wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
