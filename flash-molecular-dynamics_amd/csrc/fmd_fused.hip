@@ -2247,8 +2247,9 @@ struct Workspace {
   int64_t total;
 };
 
+constexpr int MAX_SPLIT = 32;  // workgroups per molecule (small batches: 8 molecules x 32 = 256 workgroups)
 int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
-  if (d->n_split > 0) return d->n_split > 8 ? 8 : d->n_split;
+  if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
   int cus = 256;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -2257,7 +2258,7 @@ int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
   }
   int64_t s = n_mol > 0 ? (cus + n_mol - 1) / n_mol : 1;
   if (s < 1) s = 1;
-  if (s > 8) s = 8;
+  if (s > MAX_SPLIT) s = MAX_SPLIT;
   return (int)s;
 }
 
@@ -2527,7 +2528,7 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
                                               int64_t n_nodes, int64_t max_pairs_per_mol) {
   if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0 || max_pairs_per_mol < 0) return FMD_EINVAL;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
-  const int split = desc->n_split > 0 ? (desc->n_split > 8 ? 8 : desc->n_split) : 8;
+  const int split = resolve_split(desc, n_mol);  // the slabs scale with it; >= 2 for the feature-split mode
   return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
 }
 

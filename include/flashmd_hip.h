@@ -170,7 +170,7 @@ typedef struct fmd_schnet_desc {
   int32_t out_width[4];  /* widths after each output linear, last = 1 */
   int32_t embedding_size;
   int32_t precision;
-  int32_t n_split;       /* workgroups per molecule in the pair kernels; 0 = auto (CUs / n_mol, 1..8) */
+  int32_t n_split;       /* workgroups per molecule in the pair kernels; 0 = auto (CUs / n_mol, 1..32) */
   float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
   float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
 } fmd_schnet_desc;
