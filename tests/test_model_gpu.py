@@ -122,7 +122,7 @@ def test_fused_engine_is_the_path_taken_and_deterministic(params):
     print(f"8x269 fused engine vs fp64 oracle: energy {re:.2e} forces {rf:.2e}")
     assert re < 1e-4 and rf < 1e-4
     # n_split must not change the physics (different partial-sum grouping only)
-    for ns in (1, 3):
+    for ns in (1, 3, 32):
         eng2 = engine.FusedSchNetEngine(model, n_split=ns)
         e3, f3 = eng2.energy_forces(P, T, Q, 269)
         assert _relerr(e3, f3, e_o.numpy(), f_o.numpy())[1] < 1e-4
