@@ -483,8 +483,13 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
-  int* rowstart = reinterpret_cast<int*>(sz + n);  // [n + 1]: counts, then padded exclusive offsets
-  __shared__ int wave_tot[16], real_tot[16];
+  int* cnt = reinterpret_cast<int*>(sz + n);   // [n]     pairs of row i (j > i)
+  int* rowstart = cnt + n;                      // [n + 1] offset of the row's run
+  int* rowend = rowstart + n + 1;               // [n]     end of the run including its pad entries
+  int* conf = rowend + n;                       // [n]     row i must not share an 8-entry segment with the row before
+  int* headj = conf + n;                        // [n][4]  first neighbours of the row
+  int* tailj = headj + 4 * n;                   // [n][4]  neighbours in the row's last group of four
+  __shared__ int tot_s[2], chain[256];
   for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
@@ -496,49 +501,113 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     return d2 < rc2;
   };
-  // ---- pass 1: row counts
+  // ---- pass 1: row counts, the first four neighbours and the neighbours of the last group of four
   for (int i = wv; i < n; i += 16) {
     int c = 0;
     for (int j0 = i + 1; j0 < n; j0 += 64) {
       const int j = j0 + lane;
       float d2;
       const bool hh = j < n && hit(i, j, d2);
-      c += __popcll(__ballot(hh));
+      const unsigned long long mk = __ballot(hh);
+      const int rank = c + __popcll(mk & ((1ull << lane) - 1ull));
+      if (hh && rank < 4) headj[4 * i + rank] = j;
+      c += __popcll(mk);
     }
-    if (lane == 0) rowstart[i] = c;
+    const int r = c ? ((c - 1) & 3) + 1 : 0;  // real entries in the last group
+    int found = 0;
+    for (int j1 = n; found < r && j1 > i + 1; j1 -= 64) {  // descending sweep: candidates j1-64 .. j1-1
+      const int j = j1 - 64 + lane;
+      float d2;
+      const bool hh = j > i && hit(i, j, d2);
+      const unsigned long long mk = __ballot(hh);
+      const int rank = found + __popcll(mk >> lane) - 1;  // rank from the top (this lane included)
+      if (hh && rank < r) tailj[4 * i + rank] = j;
+      found += __popcll(mk);
+    }
+    if (lane == 0) cnt[i] = c;
   }
   __syncthreads();
-  // ---- exclusive scan of the padded counts (contiguous chunk of rows per thread)
-  const int per = (n + 1023) / 1024;
-  const int i_lo = min(n, tid * per), i_hi = min(n, i_lo + per);
-  int mine = 0, mine_real = 0;
-  for (int i = i_lo; i < i_hi; ++i) {
-    mine += (rowstart[i] + 7) & ~7;
-    mine_real += rowstart[i];
+  // ---- which rows may share an 8-entry segment with the row before them: the two halves of a segment are
+  //      updated side by side, so (centre, four neighbours) of one half must be disjoint from the other half's
+  for (int i = tid; i < n; i += 1024) {
+    int cf = 0;
+    const int c = cnt[i];
+    if (c > 0) {
+      int p = i - 1;
+      while (p >= 0 && cnt[p] == 0) --p;
+      if (p >= 0) {
+        const int cp = cnt[p], rp = ((cp - 1) & 3) + 1, hn = min(c, 4);
+        for (int x = -1; x < rp && !cf; ++x) {
+          const int tv = x < 0 ? p : tailj[4 * p + x];
+          if (tv == i) cf = 1;
+          for (int y = 0; y < hn; ++y) cf |= tv == headj[4 * i + y];
+        }
+      }
+    }
+    conf[i] = cf;
   }
-  int incl = mine;
+  __syncthreads();
+  // ---- offsets: every run is padded to a multiple of FOUR entries; a run that would start in the second half of
+  //      an 8-entry segment whose first half belongs to a conflicting row is pushed to the next segment (the gap
+  //      becomes pad entries of the row before); the total is padded to a multiple of 8.
+  //      Done by one wave in three short steps instead of one 269-step loop: the only state a row inherits is
+  //      whether it starts in the second half of a segment, so each lane runs its chunk of rows for both start
+  //      states, lane by lane the chunk results are chained, and each lane replays its chunk from the right state.
+  if (wv == 0) {
+    const int chunk = (n + 63) >> 6, lo_r = min(n, lane * chunk), hi_r = min(n, lo_r + chunk);
+    int dl[2], es[2], last_ne = -1, real = 0;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  int real_w = mine_real;
+    for (int s0 = 0; s0 < 2; ++s0) {
+      int st = s0, delta = 0;
+      for (int i = lo_r; i < hi_r; ++i) {
+        const int c = cnt[i];
+        if (c == 0) continue;
+        if (st && conf[i]) { delta += 4; st = 0; }
+        const int pad = (c + 3) & ~3;
+        delta += pad;
+        st ^= (pad >> 2) & 1;
+        if (s0 == 0) { last_ne = i; real += c; }
+      }
+      dl[s0] = delta;
+      es[s0] = st;
+    }
+    chain[4 * lane] = dl[0];
+    chain[4 * lane + 1] = dl[1];
+    chain[4 * lane + 2] = es[0] | (es[1] << 1);
+    chain[4 * lane + 3] = last_ne;
+    // (same wave: LDS operations complete in order)
+    int base = 0, st = 0, prev = -1;
+    for (int l = 0; l < lane; ++l) {
+      const int e = chain[4 * l + 2], ln = chain[4 * l + 3];
+      base += chain[4 * l + st];
+      st = (e >> st) & 1;
+      if (ln >= 0) prev = ln;
+    }
+    int off = base;
+    for (int i = lo_r; i < hi_r; ++i) {
+      const int c = cnt[i];
+      rowstart[i] = off;
+      if (c == 0) continue;
+      if ((off & 4) && conf[i]) off += 4;
+      rowstart[i] = off;
+      if (prev >= 0) rowend[prev] = off;
+      off += (c + 3) & ~3;
+      prev = i;
+    }
+    // totals: the last lane's end state; real pairs summed over the wave
+    int real_w = real;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) real_w += __shfl_xor(real_w, o, 64);
-  if (lane == 63) wave_tot[wv] = incl;
-  if (lane == 0) real_tot[wv] = real_w;
-  __syncthreads();
-  int base = incl - mine;
-  for (int q = 0; q < wv; ++q) base += wave_tot[q];
-  int total = 0;
-  for (int q = 0; q < 16; ++q) total += wave_tot[q];
-  __syncthreads();  // every thread has read the counts it needs before they are overwritten
-  for (int i = i_lo; i < i_hi; ++i) {
-    const int c = rowstart[i];
-    rowstart[i] = base;  // padded offset of the row (pass 2 recounts while filling)
-    base += (c + 7) & ~7;
+    for (int o = 32; o > 0; o >>= 1) real_w += __shfl_xor(real_w, o, 64);
+    if (lane == 63) {
+      const int tot = (off + 7) & ~7;
+      if (prev >= 0) rowend[prev] = tot;
+      rowstart[n] = tot;
+      tot_s[0] = tot;
+      tot_s[1] = real_w;
+    }
   }
   __syncthreads();
+  const int total = tot_s[0];
   // ---- pass 2: fill (ballot-compacted, sorted by j), cutoff values computed once per pair here
   uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
   uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
@@ -546,6 +615,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   float* c_out = pc + (int64_t)m * cap;
   float* dc_out = pdc + (int64_t)m * cap;
   for (int i = wv; i < n; i += 16) {
+    if (cnt[i] == 0) continue;
     int k = rowstart[i];
     for (int j0 = i + 1; j0 < n; j0 += 64) {
       const int j = j0 + lane;
@@ -567,7 +637,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       }
       k += __popcll(mk);
     }
-    const int kend = (k + 7) & ~7;  // pad the centre's run to a multiple of 8 with (i, i), C = 0
+    const int kend = rowend[i];  // pad entries (i, i), C = 0: to the next run (at most 3 + 4 of them)
     if (k + lane < kend && k + lane < cap) {
       oi_out[k + lane] = (uint32_t)i * (F * 4);
       oj_out[k + lane] = (uint32_t)i * (F * 4);
@@ -590,8 +660,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     }
   }
   if (tid == 0) {
-    int real = 0;
-    for (int q = 0; q < 16; ++q) real += real_tot[q];
+    const int real = tot_s[1];
     npairs[m] = min(total, cap) & ~7;
     if (total > cap) status[0] = FMD_ECAPACITY;
     atomicMax(&status[1], total);
@@ -602,6 +671,19 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
 // ---------------------------------------------------------------------------------------------
 // edge kernels
 // ---------------------------------------------------------------------------------------------
+// Centre-row sum of a segment.  A 32-entry tile is four 8-entry segments; the lower and the upper lane half hold
+// four entries each (register r = 4q + e <-> entry 8q + 4h + e).  Usually both halves belong to one centre and the
+// centre row gets the sum over all eight entries (both halves then store the same value to the same address).  Where
+// a centre's run ends on a 4-entry boundary the other half may belong to the next centre: pairs_kernel only pairs
+// them when (centre, neighbours) of the two halves are disjoint, and each half then keeps its own sum.
+__device__ __forceinline__ float fmd_segment_sum(float si, uint32_t centre_off) {
+  const auto c = __builtin_amdgcn_permlane32_swap(centre_off, centre_off, false, false);
+  const unsigned u = __builtin_bit_cast(unsigned, si);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float both = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  return (unsigned)c[0] == (unsigned)c[1] ? both : si;
+}
+
 // Workgroup -> (molecule, split), XCD aware.  Workgroups are dealt to the 8 XCDs round-robin in linear-id order
 // (id = blockIdx.y * gridDim.x + blockIdx.x), and every XCD has its own L2.  The S workgroups of one molecule
 // gather the same x1 / d(agg) rows, so they are given ids that are equal mod 8: ids are taken in groups of
@@ -768,9 +850,9 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         *reinterpret_cast<float*>(aggb + oj_c[4 * q + e]) = vj[e] + xi_c[4 * q + e] * Wq[e];
-      si = fmd_xor32_sum(si);
+      si = fmd_segment_sum(si, oi_c[4 * q]);
       float* ci = reinterpret_cast<float*>(aggb + oi_c[4 * q]);
-      *ci += si;  // both halves store the same value to the same address
+      *ci += si;  // same centre in both halves: both store the same value to the same address
     }
   };
 
@@ -944,7 +1026,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
             si = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) si += X.xj[4 * q + e] * Wq[e];
-            so = __shfl_xor(si, 32, 64);
+            so = fmd_segment_sum(si, X.oi[q]) - si;  // the other half's share (0 when it belongs to another centre)
           } else if constexpr (ph == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1213,7 +1295,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wq[e];
-          si = fmd_xor32_sum(si);
+          si = fmd_segment_sum(si, X.oi[q]);
           // both halves store the same value to the same address
           *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
         });
@@ -1651,7 +1733,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wq[e];
-            si = fmd_xor32_sum(si);
+            si = fmd_segment_sum(si, X.oi[q]);
             *reinterpret_cast<float*>(gx1b + lo(X.oi[q])) = cval + si;
           });
         }
@@ -1846,7 +1928,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           *reinterpret_cast<float*>(gx1b + oj_c[4 * q + e]) = vj[e] + gi[4 * q + e] * Wq[e];
-        si = fmd_xor32_sum(si);
+        si = fmd_segment_sum(si, oi_c[4 * q]);
         float* ci = reinterpret_cast<float*>(gx1b + oi_c[4 * q]);
         *ci += si;
       }
@@ -2560,7 +2642,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
   auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
-  const size_t lds_pairs = (3 * max_beads_per_mol + max_beads_per_mol + 1) * sizeof(float);
+  const size_t lds_pairs = (3 * max_beads_per_mol + 13 * max_beads_per_mol + 1) * sizeof(float);
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
