@@ -1127,12 +1127,15 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
 // features per row, so each of the molecule's TWO workgroups keeps 64 features of it (blockIdx.x = which half),
 // walks ALL tiles, stages the full hidden tile (the producers' work is done twice per molecule) and runs two
 // consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
-template <int NS0, bool STAMP, bool HALF, bool FS>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
+// SH: the tile's Gaussians are computed once, by the consumers (consumer w: k-step w) between barriers B and A,
+// and reach the producers as split fragments in LDS (see the backward kernel); used when the region fits.
+template <int NS0, bool STAMP, bool HALF, bool FS, bool SH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
-  float* agg = smem + TILE_FLOATS + 128;                         // [n][128] (same offset as the other kernels)
+  float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
+  float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
@@ -1164,14 +1167,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0];
-      f32x4 cen[2 * NS0], b0r[4];
+      f32x4 cen[SH ? 1 : 2 * NS0], b0r[4];
       const float gl = a.gamma * LOG2E;
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
         if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
-        cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
-        cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
+        if (!SH) {
+          cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
+          cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h);
@@ -1186,7 +1191,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
           f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
-          rbf_fragments<false, HALF>(d, gl, cen[2 * s], cen[2 * s + 1], bh, bl, ph, pl);
+          if (SH) {
+            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
+            if (!HALF) bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
+          } else {
+            rbf_fragments<false, HALF>(d, gl, cen[SH ? 0 : 2 * s], cen[SH ? 0 : 2 * s + 1], bh, bl, ph, pl);
+          }
           mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, acc1, acc2);
         }
 #pragma unroll
@@ -1215,7 +1226,9 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
+      if (SH) __syncthreads();  // fragments of the first tile visible
       compute(T0 + S);
+      if (SH) __syncthreads();  // ... and consumed: the consumers write the second tile's
       put();
       __syncthreads();  // A(first)
       for (int t = T0; t < ntiles; t += S) {
@@ -1303,6 +1316,34 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
       // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
       // between the two barriers where the producers only write LDS.
+      // SH: Gaussians of one tile (k-step w of this wave) as split fragments in LDS
+      float d_m = 0.f;
+      f32x4 cs0, cs1;
+      if (SH && w < NS0) {
+        cs0 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h);
+        cs1 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h + 4);
+      }
+      auto fetch_d = [&](int t) {
+        if (SH) d_m = pdist[min(t * 32, last_base) + c32];
+      };
+      auto share_fragments = [&]() {  // of the tile whose distances were fetched last
+        if (SH && w < NS0 && 2 * w + h < a.nb) {
+          f16x8 bh, bl, ph, pl;
+          rbf_fragments<false, HALF>(d_m, a.gamma * LOG2E, cs0, cs1, bh, bl, ph, pl);
+          const int blk = 2 * w + h;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
+          if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
+        }
+      };
+      if (SH) {
+        fetch_d(T0);
+        share_fragments();
+        fetch_d(T0 + S);
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+        fetch_d(T0 + 2 * S);
+      }
       fetch_meta(T0);
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
       f32x16 fl_prev = zero16();
@@ -1339,6 +1380,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         FMD_STAMP(ts2)
         __syncthreads();  // B(t): hidden tiles consumed
         FMD_STAMP(ts1)
+        if (SH) {  // the producers only write the hidden tile now: the fragments they stage from next are replaced
+          share_fragments();
+          fetch_d(t + 3 * S);
+        }
         __syncthreads();  // A(t+S)
         FMD_STAMP(ts3)
       }
@@ -2402,11 +2447,17 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
     } else {
       constexpr int NS0 = (2 * KS0 + 15) / 16;
       const bool half = d->precision == FMD_PREC_W16A16;
-      if (ea.fs && half) edge_fwd_split_kernel<NS0, false, true, true><<<grid, 512, lds, s>>>(ea);
-      else if (ea.fs) edge_fwd_split_kernel<NS0, false, false, true><<<grid, 512, lds, s>>>(ea);
-      else if (half) edge_fwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(ea);
-      else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(ea);
-      else edge_fwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(ea);
+      // shared-Gaussian form when its fragment region fits next to the aggregate
+      const size_t lds_fsh = (size_t)(TILE_FLOATS + 128 + ea.nb * 256 + ea.max_beads * F) * sizeof(float);
+      const char* mode_fsh = getenv("FMD_EDGE_FWD_SHARE");  // experiments: "0" disables
+      const bool fsh = !ea.fs && !ea.stamps && lds_fsh <= MAX_LDS_BYTES && !(mode_fsh && mode_fsh[0] == '0');
+      if (ea.fs && half) edge_fwd_split_kernel<NS0, false, true, true, false><<<grid, 512, lds, s>>>(ea);
+      else if (ea.fs) edge_fwd_split_kernel<NS0, false, false, true, false><<<grid, 512, lds, s>>>(ea);
+      else if (fsh && half) edge_fwd_split_kernel<NS0, false, true, false, true><<<grid, 512, lds_fsh, s>>>(ea);
+      else if (fsh) edge_fwd_split_kernel<NS0, false, false, false, true><<<grid, 512, lds_fsh, s>>>(ea);
+      else if (half) edge_fwd_split_kernel<NS0, false, true, false, false><<<grid, 512, lds, s>>>(ea);
+      else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false, false, false><<<grid, 512, lds, s>>>(ea);
+      else edge_fwd_split_kernel<NS0, false, false, false, false><<<grid, 512, lds, s>>>(ea);
     }
   } else {
     const bool first = (l == L - 1), need = (l > 0);
@@ -2484,11 +2535,13 @@ hipError_t set_edge_attrs(size_t lds) {
   if (e != hipSuccess) return e;
   {
     constexpr int NSF = (2 * KS0 + 15) / 16;
-    const void* fwd[] = {(const void*)edge_fwd_split_kernel<NSF, false, false, false>,
-                         (const void*)edge_fwd_split_kernel<NSF, true, false, false>,
-                         (const void*)edge_fwd_split_kernel<NSF, false, true, false>,
-                         (const void*)edge_fwd_split_kernel<NSF, false, false, true>,
-                         (const void*)edge_fwd_split_kernel<NSF, false, true, true>};
+    const void* fwd[] = {(const void*)edge_fwd_split_kernel<NSF, false, false, false, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, true, false, false, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, true, false, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, false, true, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, true, true, false>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, false, false, true>,
+                         (const void*)edge_fwd_split_kernel<NSF, false, true, false, true>};
     for (const void* f : fwd) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
       if (e != hipSuccess) return e;
