@@ -1746,19 +1746,19 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         f32x16 fl;
 #pragma unroll
         for (int r = 0; r < 16; ++r) fl[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
-        // gW = x1[i] g[j] + x1[j] g[i], split (register = hi | lo << 16)
-        f16x2 gwp[16];
+        // gW = x1[i] g[j] + x1[j] g[i], split two values at a time: gwh[p] = hi halves of entries 2p, 2p+1,
+        // gwl[p] = their lo halves
+        f16x2 gwh[8], gwl[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float gw = X.xi[r >> 2] * X.gj[r] + X.xj[r] * X.gi[r >> 2];
-          if (HALF) {
-            gwp[r] = f16x2{(_Float16)gw, (_Float16)0.0f};
-          } else {
-            const hv2 h1 = __builtin_amdgcn_cvt_pkrtz(gw, 0.0f);
-            const float rem = (gw - (float)h1[0]) * SPLIT_SCALE;
-            const hv2 pk = __builtin_amdgcn_cvt_pkrtz(gw, rem);
-            __builtin_memcpy(&gwp[r], &pk, 4);
-          }
+        for (int p2 = 0; p2 < 8; ++p2) {
+          const int r = 2 * p2;
+          const f32x2 gw = f32x2{X.xi[r >> 2], X.xi[r >> 2]} * f32x2{X.gj[r], X.gj[r + 1]} +
+                           f32x2{X.xj[r], X.xj[r + 1]} * f32x2{X.gi[r >> 2], X.gi[r >> 2]};
+          uint32_t hw, lw = 0;
+          if (HALF) hw = half_pair(gw);
+          else split_pair(gw, hw, lw);
+          __builtin_memcpy(&gwh[p2], &hw, 4);
+          __builtin_memcpy(&gwl[p2], &lw, 4);
         }
         asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
         // The aggregate update and the refill of X need nothing from the producers: they run here,
@@ -1790,8 +1790,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_STAMP(1)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {  // ds_write_b16 of each half
-          hid_hi[tile_row(r, h) * LDH + col] = gwp[r][0];
-          if (!HALF) hid_lo[tile_row(r, h) * LDH + col] = gwp[r][1];
+          hid_hi[tile_row(r, h) * LDH + col] = gwh[r >> 1][r & 1];
+          if (!HALF) hid_lo[tile_row(r, h) * LDH + col] = gwl[r >> 1][r & 1];
         }
         FMD_STAMP(2)
         __syncthreads();  // C(t): gW visible
