@@ -2450,10 +2450,11 @@ int run_edges(const fmd_schnet_desc* d, bool fwd, int l, int L, EdgeArgs& ea, di
       // shared-Gaussian form when its fragment region fits next to the aggregate
       const size_t lds_fsh = (size_t)(TILE_FLOATS + 128 + ea.nb * 256 + ea.max_beads * F) * sizeof(float);
       const char* mode_fsh = getenv("FMD_EDGE_FWD_SHARE");  // experiments: "0" disables
-      const bool fsh = !ea.fs && !ea.stamps && lds_fsh <= MAX_LDS_BYTES && !(mode_fsh && mode_fsh[0] == '0');
+      // (not in W16A16: without operand splits the Gaussians are cheap for the producers, and the consumers'
+      //  extra work between B and A costs more than it saves: 0.156 vs 0.144 ms)
+      const bool fsh = !ea.fs && !half && !ea.stamps && lds_fsh <= MAX_LDS_BYTES && !(mode_fsh && mode_fsh[0] == '0');
       if (ea.fs && half) edge_fwd_split_kernel<NS0, false, true, true, false><<<grid, 512, lds, s>>>(ea);
       else if (ea.fs) edge_fwd_split_kernel<NS0, false, false, true, false><<<grid, 512, lds, s>>>(ea);
-      else if (fsh && half) edge_fwd_split_kernel<NS0, false, true, false, true><<<grid, 512, lds_fsh, s>>>(ea);
       else if (fsh) edge_fwd_split_kernel<NS0, false, false, false, true><<<grid, 512, lds_fsh, s>>>(ea);
       else if (half) edge_fwd_split_kernel<NS0, false, true, false, false><<<grid, 512, lds, s>>>(ea);
       else if (ea.stamps) edge_fwd_split_kernel<NS0, true, false, false, false><<<grid, 512, lds, s>>>(ea);
@@ -2540,8 +2541,7 @@ hipError_t set_edge_attrs(size_t lds) {
                          (const void*)edge_fwd_split_kernel<NSF, false, true, false, false>,
                          (const void*)edge_fwd_split_kernel<NSF, false, false, true, false>,
                          (const void*)edge_fwd_split_kernel<NSF, false, true, true, false>,
-                         (const void*)edge_fwd_split_kernel<NSF, false, false, false, true>,
-                         (const void*)edge_fwd_split_kernel<NSF, false, true, false, true>};
+                         (const void*)edge_fwd_split_kernel<NSF, false, false, false, true>};
     for (const void* f : fwd) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES);
       if (e != hipSuccess) return e;
