@@ -402,3 +402,24 @@ def test_wrong_bead_bound_is_flagged_not_faulted(params):
     assert int(eng.status[0]) == 0
     e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
     assert _relerr(e, f, e_o.numpy(), f_o.numpy())[1] < 1e-4
+
+
+@pytest.mark.parametrize("bond", [3.8, 1.6])
+def test_fused_engine_chain_geometries(params, bond):
+    """Chain molecules: with 3.8-long bonds a bead has one or two neighbours inside the cutoff, so nearly every
+    4-entry run of the pair list conflicts with the next one (the next centre IS the tail neighbour) and the list
+    builder has to insert its pad groups; with 1.6-long bonds the runs are long and mostly share segments.  Both
+    against the fp64 oracle, plus reproducibility."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, synthetic
+
+    pos, types, ptr = synthetic.chain_batch(5, 120, bond=bond)
+    types = types + 1
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    print(f"chain bond {bond}: energy {re:.2e} forces {rf:.2e}, pairs {int(eng.status[2])}")
+    assert re < 1e-4 and rf < 1e-4
+    e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    assert torch.equal(e, e2) and torch.equal(f, f2)
