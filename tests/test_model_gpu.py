@@ -423,3 +423,32 @@ def test_fused_engine_chain_geometries(params, bond):
     assert re < 1e-4 and rf < 1e-4
     e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
     assert torch.equal(e, e2) and torch.equal(f, f2)
+
+
+def test_fused_engine_random_ragged_batches(params):
+    """Forty random molecules (2..90 beads, densities from almost no neighbours to everything inside the cutoff) in
+    one ragged batch: the pair-list builder's padding / conflict logic sees every run-length pattern."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(123)
+    mols, sizes = [], []
+    for k in range(40):
+        n = int(torch.randint(2, 91, (1,), generator=g))
+        radius = float(1.0 + 9.0 * torch.rand(1, generator=g))
+        x = torch.randn(n, 3, generator=g)
+        x = x / x.norm(dim=1, keepdim=True) * radius * torch.rand(n, 1, generator=g) ** (1 / 3)
+        mols.append(x)
+        sizes.append(n)
+    pos = torch.cat(mols)
+    # keep beads apart (the model is smooth anyway; this only avoids d -> 0 in the oracle's normalisation)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    types = torch.randint(1, 20, (pos.shape[0],), generator=g)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    src, _ = so.radius_graph(pos, ptr, 5.0)
+    assert int(eng.status[0]) == 0 and int(eng.status[2]) == src.numel() // 2
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    print(f"40 random ragged molecules: energy {re:.2e} forces {rf:.2e}, pairs {int(eng.status[2])}")
+    assert re < 1e-4 and rf < 1e-4
