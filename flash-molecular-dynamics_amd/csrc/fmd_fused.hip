@@ -45,7 +45,7 @@ struct BlockOff {
   int64_t q0ch, q0cl;                      // W0 with column k scaled by (centre_k - cutoff/2): backward only
 };
 struct PackLayout {
-  int64_t emb, centers, blocks, block_stride, outs, out_stride, total;
+  int64_t emb, centers, blocks, block_stride, outs, out_stride, emb_x1, total;
 };
 constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // [wave][k-step of 16][lane] x 8 halves (16 B), K padded to 64
 constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
@@ -60,7 +60,8 @@ PackLayout pack_layout(const fmd_schnet_desc* d) {
   L.block_stride = BLOCK_FLOATS;
   L.outs = L.blocks + (int64_t)d->num_blocks * BLOCK_FLOATS;
   L.out_stride = OUT_FLOATS;
-  L.total = L.outs + (int64_t)d->num_out * OUT_FLOATS;
+  L.emb_x1 = L.outs + (int64_t)d->num_out * OUT_FLOATS;  // [embedding_size][128]: embedding lin1(block 0)^T
+  L.total = L.emb_x1 + (int64_t)d->embedding_size * F;
   return L;
 }
 BlockOff block_off(const PackLayout& L, int l) {
@@ -458,10 +459,11 @@ __device__ __forceinline__ void rows_to_lds(float* buf, const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // pair list: undirected i<j, strict d2 < rc2 with unfused fp32, sorted by centre i then j.
-// Each centre's entries are padded to a multiple of 8 (pad = (i,i) with d = rc, whose cutoff is 0),
-// so an 8-entry SEGMENT of a 32-entry tile always belongs to one centre: inside a segment the
-// neighbours j are distinct and the centre is shared, which lets the edge kernels accumulate with
-// plain LDS read-modify-write (no float atomics) and one in-register reduction per segment.
+// Each centre's entries are padded to a multiple of 4 (pad = (i,i) with d = rc, whose cutoff is 0), so a
+// 4-entry half of an 8-entry SEGMENT of a 32-entry tile always belongs to one centre, and both halves do
+// unless the rows are disjoint (see the conflict flags below): inside a segment the neighbours j are
+// distinct, which lets the edge kernels accumulate with plain LDS read-modify-write (no float atomics) and
+// one in-register reduction per segment.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ pos,
                                                     const int64_t* __restrict__ mol_ptr, float rc2,
@@ -470,8 +472,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ status, int max_beads) {
-  // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin):
-  // lanes sweep the candidates j > i 64 at a time from LDS, hits are counted / compacted with a ballot.
+  // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin): the row's
+  // candidates j > i are tested 64 at a time, the ballots are kept as hit masks in LDS and drive the fill.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
@@ -487,8 +489,9 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   int* rowstart = cnt + n;                      // [n + 1] offset of the row's run
   int* rowend = rowstart + n + 1;               // [n]     end of the run including its pad entries
   int* conf = rowend + n;                       // [n]     row i must not share an 8-entry segment with the row before
-  int* headj = conf + n;                        // [n][4]  first neighbours of the row
-  int* tailj = headj + 4 * n;                   // [n][4]  neighbours in the row's last group of four
+  const int NC = (n + 63) >> 6;                 // 64-candidate chunks of a row (at most 9: 535 beads)
+  // [n][NC] hit masks: bit b of masks[i NC + c] <-> (i, 64 c + b) is a pair; chunks below (i + 1) / 64 are not written
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((7 * n + 2) & ~1));
   __shared__ int tot_s[2], chain[256];
   for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
@@ -496,55 +499,74 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     sz[i] = pos[3 * (a0 + i) + 2];
   }
   __syncthreads();
-  auto hit = [&](int i, int j, float& d2) {
+  auto dist2 = [&](int i, int j) {
     const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
-    d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-    return d2 < rc2;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
   };
-  // ---- pass 1: row counts, the first four neighbours and the neighbours of the last group of four
-  for (int i = wv; i < n; i += 16) {
-    int c = 0;
-    for (int j0 = i + 1; j0 < n; j0 += 64) {
-      const int j = j0 + lane;
-      float d2;
-      const bool hh = j < n && hit(i, j, d2);
-      const unsigned long long mk = __ballot(hh);
-      const int rank = c + __popcll(mk & ((1ull << lane) - 1ull));
-      if (hh && rank < 4) headj[4 * i + rank] = j;
-      c += __popcll(mk);
+  // ---- pass 1: the hit masks and row counts.  A lane keeps its candidates j = 64 c + lane in registers (beads
+  //      beyond the molecule sit at 1e30: their d2 is +inf and never a hit), a wave takes one centre row at a time.
+  {
+    float px[9], py[9], pz[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int j = 64 * c + lane;
+      const bool ok = j < n;
+      px[c] = ok ? sx[j] : 1e30f;
+      py[c] = ok ? sy[j] : 1e30f;
+      pz[c] = ok ? sz[j] : 1e30f;
     }
-    const int r = c ? ((c - 1) & 3) + 1 : 0;  // real entries in the last group
-    int found = 0;
-    for (int j1 = n; found < r && j1 > i + 1; j1 -= 64) {  // descending sweep: candidates j1-64 .. j1-1
-      const int j = j1 - 64 + lane;
-      float d2;
-      const bool hh = j > i && hit(i, j, d2);
-      const unsigned long long mk = __ballot(hh);
-      const int rank = found + __popcll(mk >> lane) - 1;  // rank from the top (this lane included)
-      if (hh && rank < r) tailj[4 * i + rank] = j;
-      found += __popcll(mk);
+    for (int i = wv; i < n; i += 16) {
+      const float xi = sx[i], yi = sy[i], zi = sz[i];
+      const int c_first = (i + 1) >> 6;
+      int c_tot = 0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        if (c >= c_first && c < NC) {
+          const float dx = __fsub_rn(px[c], xi), dy = __fsub_rn(py[c], yi), dz = __fsub_rn(pz[c], zi);
+          const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2);
+          if (lane == 0) masks[i * NC + c] = mk;
+          c_tot += __popcll(mk);
+        }
+      }
+      if (lane == 0) cnt[i] = c_tot;
     }
-    if (lane == 0) cnt[i] = c;
   }
   __syncthreads();
   // ---- which rows may share an 8-entry segment with the row before them: the two halves of a segment are
-  //      updated side by side, so (centre, four neighbours) of one half must be disjoint from the other half's
+  //      updated side by side, so the centre and the (at most four) first neighbours of row i must not appear among
+  //      the neighbours in the last group of four of the row before (centres ascend, so they cannot meet otherwise)
   for (int i = tid; i < n; i += 1024) {
-    int cf = 0;
+    bool cf = false;
     const int c = cnt[i];
     if (c > 0) {
       int p = i - 1;
       while (p >= 0 && cnt[p] == 0) --p;
       if (p >= 0) {
-        const int cp = cnt[p], rp = ((cp - 1) & 3) + 1, hn = min(c, 4);
-        for (int x = -1; x < rp && !cf; ++x) {
-          const int tv = x < 0 ? p : tailj[4 * p + x];
-          if (tv == i) cf = 1;
-          for (int y = 0; y < hn; ++y) cf |= tv == headj[4 * i + y];
+        const int rp = ((cnt[p] - 1) & 3) + 1;
+        int tn = 0;
+        for (int cc = NC - 1; cc >= ((p + 1) >> 6) && tn < rp && !cf; --cc) {
+          unsigned long long mk = masks[p * NC + cc];
+          while (mk && tn < rp) {
+            const int bt = 63 - __clzll((long long)mk);
+            mk ^= 1ull << bt;
+            ++tn;
+            const int tv = 64 * cc + bt;
+            cf |= tv == i;
+            int hn = 0;
+            for (int c2 = (i + 1) >> 6; c2 < NC && hn < 4; ++c2) {
+              unsigned long long m2 = masks[i * NC + c2];
+              while (m2 && hn < 4) {
+                cf |= 64 * c2 + __ffsll((long long)m2) - 1 == tv;
+                m2 &= m2 - 1;
+                ++hn;
+              }
+            }
+          }
         }
       }
     }
-    conf[i] = cf;
+    conf[i] = cf ? 1 : 0;
   }
   __syncthreads();
   // ---- offsets: every run is padded to a multiple of FOUR entries; a run that would start in the second half of
@@ -608,7 +630,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
   __syncthreads();
   const int total = tot_s[0];
-  // ---- pass 2: fill (ballot-compacted, sorted by j), cutoff values computed once per pair here
+  // ---- pass 2: fill from the masks (sorted by j)
   uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
   uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
   float* d_out = pd + (int64_t)m * cap;
@@ -617,22 +639,13 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   for (int i = wv; i < n; i += 16) {
     if (cnt[i] == 0) continue;
     int k = rowstart[i];
-    for (int j0 = i + 1; j0 < n; j0 += 64) {
-      const int j = j0 + lane;
-      float d2 = 0.f;
-      const bool hh = j < n && hit(i, j, d2);
-      const unsigned long long mk = __ballot(hh);
-      if (hh) {
+    for (int c = (i + 1) >> 6; c < NC; ++c) {
+      const unsigned long long mk = masks[i * NC + c];
+      if ((mk >> lane) & 1ull) {
         const int kk = k + __popcll(mk & ((1ull << lane) - 1ull));
         if (kk < cap) {
-          const float d = sqrtf(d2);
-          float C, dC;
-          fmd_cutoff2(d, rc, C, dC);
           oi_out[kk] = (uint32_t)i * (F * 4);
-          oj_out[kk] = (uint32_t)j * (F * 4);
-          d_out[kk] = d;
-          c_out[kk] = C;
-          dc_out[kk] = dC;
+          oj_out[kk] = (uint32_t)(64 * c + lane) * (F * 4);
         }
       }
       k += __popcll(mk);
@@ -641,10 +654,21 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     if (k + lane < kend && k + lane < cap) {
       oi_out[k + lane] = (uint32_t)i * (F * 4);
       oj_out[k + lane] = (uint32_t)i * (F * 4);
-      d_out[k + lane] = rc;
-      c_out[k + lane] = 0.f;
-      dc_out[k + lane] = 0.f;
     }
+  }
+  __syncthreads();  // (workgroup-scope release/acquire of the entries written above)
+  // ---- distances and cutoff values, one entry per lane (in a candidate sweep only one lane in five holds a pair,
+  //      so sqrt / sin / cos there would run at a fifth of the lanes)
+  for (int k = tid; k < min(total, cap); k += 1024) {
+    const uint32_t oi = oi_out[k], oj = oj_out[k];
+    float d = rc, C = 0.f, dC = 0.f;
+    if (oi != oj) {
+      d = sqrtf(dist2((int)(oi / (F * 4)), (int)(oj / (F * 4))));
+      fmd_cutoff2(d, rc, C, dC);
+    }
+    d_out[k] = d;
+    c_out[k] = C;
+    dc_out[k] = dC;
   }
   // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
   // need a validity test
@@ -2019,8 +2043,6 @@ __device__ __forceinline__ f32x16 prefetch_col(const float* __restrict__ src, in
   return v;
 }
 struct NodeFwdArgs {
-  const int64_t* types;
-  const float* emb;
   float* x;            // [N,128] in/out
   const float* slabs;  // agg partials of the previous block
   int64_t slab_stride;
@@ -2032,7 +2054,7 @@ struct NodeFwdArgs {
   int64_t n_nodes;
 };
 
-template <bool FIRST, bool SPLIT>
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
@@ -2041,48 +2063,32 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32;
-    if (FIRST) {  // x = embedding[type]
-      const int r = tid >> 3, c0 = (tid & 7) * 4;
-      const bool ok = row0 + r < a.n_nodes;
-      const int64_t ty = ok ? a.types[row0 + r] : 0;
+    const f32x16 x_old = prefetch_col(a.x, row0, a.n_nodes, col, h);
+    rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
+    __syncthreads();
+    f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);  // conv = agg lin2^T + b2
+    const float b2 = a.b2[col];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = c0 + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          v = *reinterpret_cast<const f32x4*>(a.emb + ty * F + c);
-          *reinterpret_cast<f32x4*>(a.x + (row0 + r) * F + c) = v;
-        }
-        tile_store4<SPLIT>(bufA, r, c, v);
-      }
-    } else {
-      const f32x16 x_old = prefetch_col(a.x, row0, a.n_nodes, col, h);
-      rows_to_lds<SPLIT>(bufA, a.slabs, a.slab_stride, a.n_slabs, row0, a.n_nodes, tid);
-      __syncthreads();
-      f32x16 acc = gemm_rows<SPLIT>(bufA, a.l2, w, lane);  // conv = agg lin2^T + b2
-      const float b2 = a.b2[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[r] = fmd_tanh_fast(acc[r] + b2);
-        const int64_t row = row0 + tile_row(r, h);
-        if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
-      }
-      tile_store<SPLIT>(bufB, acc, w, lane);
-      __syncthreads();
-      acc = gemm_rows<SPLIT>(bufB, a.l3, w, lane);  // y = tanh(conv) lin^T + b3 ; x += y
-      const float b3 = a.b3[col];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + tile_row(r, h);
-        float xn = 0.f;
-        if (row < a.n_nodes) {
-          xn = x_old[r] + (acc[r] + b3);
-          a.x[row * F + col] = xn;
-        }
-        acc[r] = xn;
-      }
-      tile_store<SPLIT>(bufA, acc, w, lane);
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = fmd_tanh_fast(acc[r] + b2);
+      const int64_t row = row0 + tile_row(r, h);
+      if (row < a.n_nodes) a.t_out[row * F + col] = acc[r];
     }
+    tile_store<SPLIT>(bufB, acc, w, lane);
+    __syncthreads();
+    acc = gemm_rows<SPLIT>(bufB, a.l3, w, lane);  // y = tanh(conv) lin^T + b3 ; x += y
+    const float b3 = a.b3[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + tile_row(r, h);
+      float xn = 0.f;
+      if (row < a.n_nodes) {
+        xn = x_old[r] + (acc[r] + b3);
+        a.x[row * F + col] = xn;
+      }
+      acc[r] = xn;
+    }
+    tile_store<SPLIT>(bufA, acc, w, lane);
     __syncthreads();
     const f32x16 x1 = gemm_rows<SPLIT>(bufA, a.l1, w, lane);  // x1 = x lin1^T
 #pragma unroll
@@ -2288,6 +2294,231 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
   }
 }
 
+// first node launch of a timestep: x = embedding[type], x1 = (embedding lin1^T)[type] from the packed table
+// (32 lanes x 16 bytes per bead and array)
+__global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restrict__ types,
+                                                         const float* __restrict__ emb,
+                                                         const float* __restrict__ emb_x1,
+                                                         float* __restrict__ x, float* __restrict__ x1,
+                                                         int64_t n_nodes) {
+  const int64_t total = n_nodes * 32, stride = (int64_t)gridDim.x * 256;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const int64_t n = idx >> 5;
+    const int c = (int)(idx & 31) * 4;
+    const int64_t ty = types[n];
+    *reinterpret_cast<f32x4*>(x + n * F + c) = *reinterpret_cast<const f32x4*>(emb + ty * F + c);
+    *reinterpret_cast<f32x4*>(x1 + n * F + c) = *reinterpret_cast<const f32x4*>(emb_x1 + ty * F + c);
+  }
+}
+
+// ---- register-resident, transposed-product forms of node_fwd / node_bwd (split-operand engines).
+// The streamed 32-row chains above are bound by latency and by VALU work around the GEMMs, not by the matrix
+// pipe: every stage waits for its operand fragments from L2 and every tile for its rows from HBM; every output
+// element costs a scalar tanh / split / 4-byte LDS write / 4-byte global store, every operand element a byte
+// permute.  Here
+//  * one workgroup per CU keeps the three operands of its chain in registers for all of its tiles (4 waves x 192
+//    registers; the kernel runs one wave per SIMD, so the 512-register budget is there) and requests the NEXT
+//    tile's rows before it runs the current one;
+//  * a stage computes the TRANSPOSED product  D[m = output column][n = row] = sum_k W[m][k] act[n][k]: the
+//    packed operand fragment is the MFMA A operand, the activation rows come from LDS as the B operand.  A lane
+//    then owns one row and, per group of four registers, four CONSECUTIVE output columns
+//    (register r = 4 q + e  <->  column 32 w + 8 q + 4 h + e): global loads / stores are 16 bytes wide, the bias /
+//    tanh / split arithmetic runs on packed pairs, and the next stage's operand goes to LDS as two fp16 planes
+//    (hi, lo) with 8-byte writes that the next GEMM reads back as ready 16-byte fragments (no permutes).
+constexpr int NLD = 144;              // halves per row of an activation plane (288 B: the b128 fragment reads are conflict free)
+constexpr int NPLANE = 32 * NLD;      // halves of one plane; a tile is the hi plane followed by the lo plane
+struct RowsPre {
+  f32x4 s0[4], s1[4];
+};
+__device__ __forceinline__ void rows_fetch(RowsPre& p, const float* __restrict__ src, int64_t slab_stride,
+                                           int n_slabs, int64_t row0, int64_t n_rows, int tid) {
+  const int r = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p.s0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    p.s1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row0 + r < n_rows) {
+      const float* q = src + (row0 + r) * F + c0 + 32 * i;
+      p.s0[i] = *reinterpret_cast<const f32x4*>(q);
+      if (n_slabs > 1) p.s1[i] = *reinterpret_cast<const f32x4*>(q + slab_stride);
+    }
+  }
+}
+__device__ __forceinline__ void planes_store4(_Float16* tile, int r, int c, const f32x4& v) {
+  uint32_t h0, l0, h1, l1;
+  split_pair(f32x2{v[0], v[1]}, h0, l0);
+  split_pair(f32x2{v[2], v[3]}, h1, l1);
+  *reinterpret_cast<uint2*>(tile + r * NLD + c) = uint2{h0, h1};
+  *reinterpret_cast<uint2*>(tile + NPLANE + r * NLD + c) = uint2{l0, l1};
+}
+// same summation order as rows_to_lds: ((s0 + s1) + s2) + ...
+__device__ __forceinline__ void rows_commit(_Float16* tile, const RowsPre& p, const float* __restrict__ src,
+                                            int64_t slab_stride, int n_slabs, int64_t row0, int64_t n_rows,
+                                            int tid) {
+  const int r = tid >> 3, c0 = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + 32 * i;
+    f32x4 v = p.s0[i];
+    if (n_slabs > 1) v += p.s1[i];
+    if (n_slabs > 2 && row0 + r < n_rows) {
+      const float* q = src + (row0 + r) * F + c;
+      for (int s = 2; s < n_slabs; ++s) v += *reinterpret_cast<const f32x4*>(q + s * slab_stride);
+    }
+    planes_store4(tile, r, c, v);
+  }
+}
+// this lane's 16 columns of one row of a [N,128] array (zeros when the row does not exist)
+__device__ __forceinline__ f32x16 load_cols(const float* __restrict__ src, int64_t row, bool ok, int w, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (ok) t = *reinterpret_cast<const f32x4*>(src + row * F + 32 * w + 8 * q + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+  }
+  return v;
+}
+__device__ __forceinline__ void store_cols(float* __restrict__ dst, int64_t row, bool ok, int w, int h,
+                                           const f32x16& v) {
+  if (!ok) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<f32x4*>(dst + row * F + 32 * w + 8 * q + 4 * h) =
+        f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+__device__ __forceinline__ void cols_to_planes(_Float16* tile, const f32x16& v, int w, int lane) {
+  const int r = lane & 31, c = 32 * w + 4 * (lane >> 5);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    planes_store4(tile, r, c + 8 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+}
+// three accumulators: with one wave per SIMD two dependent MFMAs in a row would stall on each other
+__device__ __forceinline__ f32x16 gemm_cols_frag(const _Float16* tile, const BFrag& wf, int lane) {
+  f32x16 a1 = zero16(), a2 = zero16(), a3 = zero16();
+  const _Float16* ph = tile + (lane & 31) * NLD + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(ph + 16 * s);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(ph + NPLANE + 16 * s);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[s], bh, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[s], bl, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.l[s], bh, a3, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a1[r] += (a2[r] + a3[r]) * SPLIT_INV;
+  return a1;
+}
+
+__global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
+  __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
+  __shared__ __attribute__((aligned(16))) _Float16 bufZ[2 * NPLANE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int64_t n_tiles = (a.n_nodes + 31) / 32;
+  int64_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  BFrag w1, w2, w3;
+  RowsPre pre;
+  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+  f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
+  load_bfrag(w2, a.l2, w, lane);
+  load_bfrag(w3, a.l3, w, lane);
+  load_bfrag(w1, a.l1, w, lane);
+  const f32x16 b2 = load_cols(a.b2, 0, true, w, h), b3 = load_cols(a.b3, 0, true, w, h);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
+    const bool ok = row < a.n_nodes;
+    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+    const f32x16 x_old = xo;
+    if (next < n_tiles) {
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, next * 32, a.n_nodes, tid);
+      xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
+    }
+    __syncthreads();
+    f32x16 acc = gemm_cols_frag(bufX, w2, lane);  // conv = agg lin2^T + b2
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 t = tanh_fast2(f32x2{acc[r], acc[r + 1]} + f32x2{b2[r], b2[r + 1]});
+      acc[r] = t[0];
+      acc[r + 1] = t[1];
+    }
+    store_cols(a.t_out, row, ok, w, h, acc);
+    cols_to_planes(bufY, acc, w, lane);
+    __syncthreads();
+    acc = gemm_cols_frag(bufY, w3, lane);  // y = tanh(conv) lin^T + b3 ; x += y
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = x_old[r] + (acc[r] + b3[r]);
+    store_cols(a.x, row, ok, w, h, acc);
+    cols_to_planes(bufZ, acc, w, lane);
+    __syncthreads();
+    const f32x16 x1 = gemm_cols_frag(bufZ, w1, lane);  // x1 = x lin1^T
+    store_cols(a.x1_out, row, ok, w, h, x1);
+    // no barrier here: bufX / bufY / bufZ are next written after the first / second / third barrier of the next
+    // tile, each of which every wave reaches only after its last read of that buffer
+  }
+}
+
+template <bool HAS_SLABS>
+__global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
+  __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
+  __shared__ __attribute__((aligned(16))) _Float16 bufZ[2 * NPLANE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int64_t n_tiles = (a.n_nodes + 31) / 32;
+  int64_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  BFrag w1, w3, w2;
+  RowsPre pre;
+  f32x16 t_nx, gx_nx;
+  auto fetch = [&](int64_t t) {
+    const int64_t row = t * 32 + nl;
+    t_nx = load_cols(a.t, row, row < a.n_nodes, w, h);
+    if (HAS_SLABS) {
+      gx_nx = load_cols(a.gx, row, row < a.n_nodes, w, h);
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, t * 32, a.n_nodes, tid);
+    } else {
+      rows_fetch(pre, a.gx, 0, 1, t * 32, a.n_nodes, tid);
+    }
+  };
+  fetch(tile);
+  if (HAS_SLABS) load_bfrag(w1, a.l1t, w, lane);
+  load_bfrag(w3, a.l3t, w, lane);
+  load_bfrag(w2, a.l2t, w, lane);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
+    const bool ok = row < a.n_nodes;
+    const f32x16 t_pre = t_nx;
+    f32x16 gx_pre;
+    if (HAS_SLABS) {
+      gx_pre = gx_nx;
+      rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+    } else {
+      rows_commit(bufY, pre, a.gx, 0, 1, tile * 32, a.n_nodes, tid);
+    }
+    if (next < n_tiles) fetch(next);
+    f32x16 acc;
+    if (HAS_SLABS) {  // gx += (sum of gx1 partials) lin1
+      __syncthreads();
+      acc = gemm_cols_frag(bufX, w1, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = gx_pre[r] + acc[r];
+      store_cols(a.gx, row, ok, w, h, acc);
+      cols_to_planes(bufY, acc, w, lane);
+    }
+    __syncthreads();
+    acc = gemm_cols_frag(bufY, w3, lane);  // d/d tanh(conv) = gx lin
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] *= 1.0f - t_pre[r] * t_pre[r];
+    cols_to_planes(bufZ, acc, w, lane);
+    __syncthreads();
+    acc = gemm_cols_frag(bufZ, w2, lane);  // d/d agg = gconv lin2
+    store_cols(a.gagg, row, ok, w, h, acc);
+    if (!HAS_SLABS) __syncthreads();  // bufY is refilled at the top of the next tile
+  }
+}
+
 // one workgroup (4 waves) per molecule: forces from dE/dd of its pairs, energy from its beads.
 // Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered inside one
 // wave); the four copies are added in fixed order, so the result is reproducible.
@@ -2375,14 +2606,18 @@ struct Workspace {
 };
 
 constexpr int MAX_SPLIT = 32;  // workgroups per molecule (small batches: 8 molecules x 32 = 256 workgroups)
-int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
-  if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
+int device_cus() {
   int cus = 256;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
+  return cus;
+}
+int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
+  if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
+  const int cus = device_cus();
   int64_t s = n_mol > 0 ? (cus + n_mol - 1) / n_mol : 1;
   if (s < 1) s = 1;
   if (s > MAX_SPLIT) s = MAX_SPLIT;
@@ -2613,6 +2848,18 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
   memset(out, 0, L.total * sizeof(float));
   memcpy(out + L.emb, wt->embedding, (size_t)desc->embedding_size * F * sizeof(float));
   for (int k = 0; k < desc->num_rbf; ++k) out[L.centers + k] = centers[k];
+  // The first block's x1 = lin1(embedding[type]) only depends on the bead type: one table row per type (fp64
+  // accumulation, rounded once), so the first node launch of a timestep is a gather instead of a GEMM.
+  if (desc->num_blocks > 0 && wt->blocks[0].lin1_w) {
+    const float* l1 = reinterpret_cast<const float*>(wt->blocks[0].lin1_w);
+    const float* em = reinterpret_cast<const float*>(wt->embedding);
+    for (int t = 0; t < desc->embedding_size; ++t)
+      for (int o = 0; o < F; ++o) {
+        double acc = 0.0;
+        for (int k = 0; k < F; ++k) acc += (double)em[(int64_t)t * F + k] * (double)l1[(int64_t)o * F + k];
+        out[L.emb_x1 + (int64_t)t * F + o] = (float)acc;
+      }
+  }
   for (int l = 0; l < desc->num_blocks; ++l) {
     const fmd_schnet_block_weights& b = wt->blocks[l];
     if (!b.lin1_w || !b.f0_w || !b.f0_b || !b.f1_w || !b.lin2_w || !b.lin2_b || !b.lin_w || !b.lin_b)
@@ -2695,7 +2942,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
   auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
-  const size_t lds_pairs = (3 * max_beads_per_mol + 13 * max_beads_per_mol + 1) * sizeof(float);
+  // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads)
+  const size_t lds_pairs =
+      (7 * max_beads_per_mol + 2 + 2 * ((max_beads_per_mol + 63) / 64) * max_beads_per_mol) * sizeof(float);
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
@@ -2728,6 +2977,12 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   int64_t ng_max = 768;
   if (const char* e = getenv("FMD_NODE_GRID")) ng_max = atoi(e) > 0 ? atoi(e) : 768;
   const unsigned node_grid = (unsigned)(n_tiles < ng_max ? n_tiles : ng_max);
+  // register-resident node_fwd / node_bwd (split-operand engines): one workgroup per CU; FMD_NODE_RES=0 selects
+  // the streamed kernels (experiments)
+  bool node_res = sp;
+  if (const char* e = getenv("FMD_NODE_RES")) node_res = sp && atoi(e) != 0;
+  const int64_t cus = device_cus();
+  const unsigned res_grid = (unsigned)(n_tiles < cus ? n_tiles : cus);
   const int64_t slab_stride = n_nodes * F;
   dim3 egrid((unsigned)split, (unsigned)n_mol);
 
@@ -2754,19 +3009,21 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   for (int l = 0; l < L; ++l) {
     const BlockOff o = block_off(PL, l);
     NodeFwdArgs na;
-    na.types = atom_types; na.emb = pk + PL.emb; na.x = ws.x; na.slabs = ws.slabs;
+    na.x = ws.x; na.slabs = ws.slabs;
     na.slab_stride = slab_stride; na.n_slabs = split; na.l1 = pk + o.l1; na.x1_out = ws.x1[l];
     na.n_nodes = n_nodes;
     na.l2 = na.b2 = na.l3 = na.b3 = nullptr; na.t_out = nullptr;
     ev_begin();
     if (l == 0) {
-      if (sp) node_fwd_kernel<true, true><<<node_grid, 256, 0, s>>>(na);
-      else node_fwd_kernel<true, false><<<node_grid, 256, 0, s>>>(na);
+      const int64_t want = (n_nodes * 32 + 255) / 256;
+      node_embed_kernel<<<(unsigned)(want < 4096 ? want : 4096), 256, 0, s>>>(atom_types, pk + PL.emb, pk + PL.emb_x1,
+                                                                          ws.x, ws.x1[0], n_nodes);
     } else {
       const BlockOff q = block_off(PL, l - 1);
       na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
-      if (sp) node_fwd_kernel<false, true><<<node_grid, 256, 0, s>>>(na);
-      else node_fwd_kernel<false, false><<<node_grid, 256, 0, s>>>(na);
+      if (node_res) node_fwd_res_kernel<<<res_grid, 256, 0, s>>>(na);
+      else if (sp) node_fwd_kernel<true><<<node_grid, 256, 0, s>>>(na);
+      else node_fwd_kernel<false><<<node_grid, 256, 0, s>>>(na);
     }
     ev_end();
     FMD_CHECK_LAUNCH();
@@ -2808,11 +3065,13 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ba.l1t = nullptr;
     ev_begin();
     if (l == L - 1) {
-      if (sp) node_bwd_kernel<false, true><<<node_grid, 256, 0, s>>>(ba);
+      if (node_res) node_bwd_res_kernel<false><<<res_grid, 256, 0, s>>>(ba);
+      else if (sp) node_bwd_kernel<false, true><<<node_grid, 256, 0, s>>>(ba);
       else node_bwd_kernel<false, false><<<node_grid, 256, 0, s>>>(ba);
     } else {
       ba.l1t = pk + block_off(PL, l + 1).l1t;
-      if (sp) node_bwd_kernel<true, true><<<node_grid, 256, 0, s>>>(ba);
+      if (node_res) node_bwd_res_kernel<true><<<res_grid, 256, 0, s>>>(ba);
+      else if (sp) node_bwd_kernel<true, true><<<node_grid, 256, 0, s>>>(ba);
       else node_bwd_kernel<true, false><<<node_grid, 256, 0, s>>>(ba);
     }
     ev_end();
