@@ -471,7 +471,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
-                                                    int32_t* __restrict__ status, int max_beads) {
+                                                    int32_t* __restrict__ status, int max_beads, float* __restrict__ forces, int ent_cap) {
   // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin): the row's
   // candidates j > i are tested 64 at a time, the ballots are kept as hit masks in LDS and drive the fill.
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -492,12 +492,14 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   const int NC = (n + 63) >> 6;                 // 64-candidate chunks of a row (at most 9: 535 beads)
   // [n][NC] hit masks: bit b of masks[i NC + c] <-> (i, 64 c + b) is a pair; chunks below (i + 1) / 64 are not written
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((7 * n + 2) & ~1));
-  __shared__ int tot_s[2], chain[256];
+  __shared__ int tot_s[2];
   for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
     sz[i] = pos[3 * (a0 + i) + 2];
   }
+  // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
+  for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
   __syncthreads();
   auto dist2 = [&](int i, int j) {
     const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
@@ -519,16 +521,19 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       const float xi = sx[i], yi = sy[i], zi = sz[i];
       const int c_first = (i + 1) >> 6;
       int c_tot = 0;
+      unsigned mlo = 0u, mhi = 0u;  // lane c collects the mask of chunk c: one LDS store per row
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         if (c >= c_first && c < NC) {
           const float dx = __fsub_rn(px[c], xi), dy = __fsub_rn(py[c], yi), dz = __fsub_rn(pz[c], zi);
           const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
           const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2);
-          if (lane == 0) masks[i * NC + c] = mk;
+          mlo = lane == c ? (unsigned)mk : mlo;
+          mhi = lane == c ? (unsigned)(mk >> 32) : mhi;
           c_tot += __popcll(mk);
         }
       }
+      if (lane < NC) masks[i * NC + lane] = ((unsigned long long)mhi << 32) | mlo;  // (zero below c_first)
       if (lane == 0) cnt[i] = c_tot;
     }
   }
@@ -538,31 +543,38 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   //      the neighbours in the last group of four of the row before (centres ascend, so they cannot meet otherwise)
   for (int i = tid; i < n; i += 1024) {
     bool cf = false;
-    const int c = cnt[i];
-    if (c > 0) {
+    if (cnt[i] > 0) {
       int p = i - 1;
       while (p >= 0 && cnt[p] == 0) --p;
       if (p >= 0) {
-        const int rp = ((cnt[p] - 1) & 3) + 1;
-        int tn = 0;
-        for (int cc = NC - 1; cc >= ((p + 1) >> 6) && tn < rp && !cf; --cc) {
-          unsigned long long mk = masks[p * NC + cc];
-          while (mk && tn < rp) {
-            const int bt = 63 - __clzll((long long)mk);
-            mk ^= 1ull << bt;
-            ++tn;
-            const int tv = 64 * cc + bt;
-            cf |= tv == i;
-            int hn = 0;
-            for (int c2 = (i + 1) >> 6; c2 < NC && hn < 4; ++c2) {
-              unsigned long long m2 = masks[i * NC + c2];
-              while (m2 && hn < 4) {
-                cf |= 64 * c2 + __ffsll((long long)m2) - 1 == tv;
-                m2 &= m2 - 1;
-                ++hn;
-              }
-            }
+        // the row's first (at most four) neighbours and the last rp of the row before, as 16-bit fields
+        unsigned long long hd = ~0ull, tl = ~0ull;
+        int hn = 0, tn = 0;
+        for (int c = (i + 1) >> 6; c < NC && hn < 4; ++c) {
+          unsigned long long m2 = masks[i * NC + c];
+          while (m2 && hn < 4) {
+            hd = (hd << 16) | (unsigned long long)(64 * c + __ffsll((long long)m2) - 1);
+            m2 &= m2 - 1;
+            ++hn;
           }
+        }
+        const int rp = ((cnt[p] - 1) & 3) + 1;
+        for (int c = NC - 1; c >= ((p + 1) >> 6) && tn < rp; --c) {
+          unsigned long long m2 = masks[p * NC + c];
+          while (m2 && tn < rp) {
+            const int bt = 63 - __clzll((long long)m2);
+            m2 ^= 1ull << bt;
+            tl = (tl << 16) | (unsigned long long)(64 * c + bt);
+            ++tn;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned tv = (unsigned)(tl >> (16 * t)) & 0xffffu;  // 0xffff: no such neighbour
+          bool hit = tv == (unsigned)i;
+#pragma unroll
+          for (int y = 0; y < 4; ++y) hit |= tv == ((unsigned)(hd >> (16 * y)) & 0xffffu);
+          cf |= tv != 0xffffu && hit;
         }
       }
     }
@@ -574,7 +586,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   //      becomes pad entries of the row before); the total is padded to a multiple of 8.
   //      Done by one wave in three short steps instead of one 269-step loop: the only state a row inherits is
   //      whether it starts in the second half of a segment, so each lane runs its chunk of rows for both start
-  //      states, lane by lane the chunk results are chained, and each lane replays its chunk from the right state.
+  //      states, the chunk functions are composed across lanes by a shuffle scan, and each lane replays its chunk
+  //      from its true start offset.
   if (wv == 0) {
     const int chunk = (n + 63) >> 6, lo_r = min(n, lane * chunk), hi_r = min(n, lo_r + chunk);
     int dl[2], es[2], last_ne = -1, real = 0;
@@ -593,18 +606,23 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       dl[s0] = delta;
       es[s0] = st;
     }
-    chain[4 * lane] = dl[0];
-    chain[4 * lane + 1] = dl[1];
-    chain[4 * lane + 2] = es[0] | (es[1] << 1);
-    chain[4 * lane + 3] = last_ne;
-    // (same wave: LDS operations complete in order)
-    int base = 0, st = 0, prev = -1;
-    for (int l = 0; l < lane; ++l) {
-      const int e = chain[4 * l + 2], ln = chain[4 * l + 3];
-      base += chain[4 * l + st];
-      st = (e >> st) & 1;
-      if (ln >= 0) prev = ln;
+    // inclusive scan over lanes of the chunk functions  state -> (added entries, end state): earlier lanes first
+    int d0 = dl[0], d1 = dl[1], nx = es[0] | (es[1] << 1), ln = last_ne;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int pd0 = __shfl_up(d0, o, 64), pd1 = __shfl_up(d1, o, 64), pnx = __shfl_up(nx, o, 64);
+      const int pln = __shfl_up(ln, o, 64);
+      if (lane >= o) {
+        const int n0 = pnx & 1, n1 = (pnx >> 1) & 1;  // the earlier part's end states
+        const int c0 = pd0 + (n0 ? d1 : d0), c1 = pd1 + (n1 ? d1 : d0);
+        nx = ((nx >> n0) & 1) | (((nx >> n1) & 1) << 1);
+        d0 = c0;
+        d1 = c1;
+        ln = max(ln, pln);
+      }
     }
+    int base = __shfl_up(d0, 1, 64), prev = __shfl_up(ln, 1, 64);  // exclusive: what the lanes before this one add
+    if (lane == 0) { base = 0; prev = -1; }
     int off = base;
     for (int i = lo_r; i < hi_r; ++i) {
       const int c = cnt[i];
@@ -636,34 +654,62 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   float* d_out = pd + (int64_t)m * cap;
   float* c_out = pc + (int64_t)m * cap;
   float* dc_out = pdc + (int64_t)m * cap;
+  // The (centre, neighbour) entries are staged in LDS as i | j << 16 when the list fits (ent_cap entries): the sweep's
+  // scattered writes (a dozen active lanes per store) then stay on chip, and the entry arrays are written once,
+  // densely, by the pass below.  A longer list is written straight to the arrays and read back.
+  uint32_t* ent = reinterpret_cast<uint32_t*>(masks + n * NC);
+  const bool staged = total <= ent_cap;
   for (int i = wv; i < n; i += 16) {
     if (cnt[i] == 0) continue;
     int k = rowstart[i];
-    for (int c = (i + 1) >> 6; c < NC; ++c) {
-      const unsigned long long mk = masks[i * NC + c];
-      if ((mk >> lane) & 1ull) {
-        const int kk = k + __popcll(mk & ((1ull << lane) - 1ull));
-        if (kk < cap) {
-          oi_out[kk] = (uint32_t)i * (F * 4);
-          oj_out[kk] = (uint32_t)(64 * c + lane) * (F * 4);
+    k = __builtin_amdgcn_readfirstlane(k);
+    const unsigned long long mrow = lane < NC ? masks[i * NC + lane] : 0ull;  // lane c: the mask of chunk c
+    const unsigned rlo = (unsigned)mrow, rhi = (unsigned)(mrow >> 32);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      if (c >= ((i + 1) >> 6) && c < NC) {
+        const unsigned lo = __builtin_amdgcn_readlane(rlo, c), hi = __builtin_amdgcn_readlane(rhi, c);
+        const unsigned long long mk = ((unsigned long long)hi << 32) | lo;  // wave-uniform: used as the execution mask
+        if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
+          const int kk = k + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+          if (staged) {
+            ent[kk] = (uint32_t)i | ((uint32_t)(64 * c + lane) << 16);
+          } else if (kk < cap) {
+            oi_out[kk] = (uint32_t)i * (F * 4);
+            oj_out[kk] = (uint32_t)(64 * c + lane) * (F * 4);
+          }
         }
+        k += __popcll(mk);
       }
-      k += __popcll(mk);
     }
     const int kend = rowend[i];  // pad entries (i, i), C = 0: to the next run (at most 3 + 4 of them)
-    if (k + lane < kend && k + lane < cap) {
-      oi_out[k + lane] = (uint32_t)i * (F * 4);
-      oj_out[k + lane] = (uint32_t)i * (F * 4);
+    if (k + lane < kend) {
+      if (staged) {
+        ent[k + lane] = (uint32_t)i | ((uint32_t)i << 16);
+      } else if (k + lane < cap) {
+        oi_out[k + lane] = (uint32_t)i * (F * 4);
+        oj_out[k + lane] = (uint32_t)i * (F * 4);
+      }
     }
   }
   __syncthreads();  // (workgroup-scope release/acquire of the entries written above)
   // ---- distances and cutoff values, one entry per lane (in a candidate sweep only one lane in five holds a pair,
   //      so sqrt / sin / cos there would run at a fifth of the lanes)
   for (int k = tid; k < min(total, cap); k += 1024) {
-    const uint32_t oi = oi_out[k], oj = oj_out[k];
+    int i, j;
+    if (staged) {
+      const uint32_t e = ent[k];
+      i = (int)(e & 0xffffu);
+      j = (int)(e >> 16);
+      oi_out[k] = (uint32_t)i * (F * 4);
+      oj_out[k] = (uint32_t)j * (F * 4);
+    } else {
+      i = (int)(oi_out[k] / (F * 4));
+      j = (int)(oj_out[k] / (F * 4));
+    }
     float d = rc, C = 0.f, dC = 0.f;
-    if (oi != oj) {
-      d = sqrtf(dist2((int)(oi / (F * 4)), (int)(oj / (F * 4))));
+    if (i != j) {
+      d = sqrtf(dist2(i, j));
       fmd_cutoff2(d, rc, C, dC);
     }
     d_out[k] = d;
@@ -2519,9 +2565,142 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
   }
 }
 
-// one workgroup (4 waves) per molecule: forces from dE/dd of its pairs, energy from its beads.
-// Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered inside one
-// wave); the four copies are added in fixed order, so the result is reproducible.
+// W16A16 output network in the transposed form: one fp16 plane (round to nearest even, the value later layers and the
+// backward see is written back to v); its GEMMs are one MFMA per k-step against the hi record (= Linear.weight.half())
+__device__ __forceinline__ void cols_to_plane_half(_Float16* tile, f32x16& v, int w, int lane) {
+  _Float16* p = tile + (lane & 31) * NLD + 32 * w + 4 * (lane >> 5);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f16x2 h0 = __builtin_convertvector(f32x2{v[4 * q], v[4 * q + 1]}, f16x2);
+    const f16x2 h1 = __builtin_convertvector(f32x2{v[4 * q + 2], v[4 * q + 3]}, f16x2);
+    v[4 * q] = (float)h0[0]; v[4 * q + 1] = (float)h0[1];
+    v[4 * q + 2] = (float)h1[0]; v[4 * q + 3] = (float)h1[1];
+    uint32_t u0, u1;
+    __builtin_memcpy(&u0, &h0, 4);
+    __builtin_memcpy(&u1, &h1, 4);
+    *reinterpret_cast<uint2*>(p + 8 * q) = uint2{u0, u1};
+  }
+}
+
+__device__ __forceinline__ f32x16 gemm_cols_half(const _Float16* tile, const BFrag& wf, int lane) {
+  f32x16 acc = zero16();
+  const _Float16* ph = tile + (lane & 31) * NLD + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[s], *reinterpret_cast<const f16x8*>(ph + 16 * s), acc, 0, 0, 0);
+  return acc;
+}
+
+// node_out in the transposed form (see node_fwd_res_kernel); its 2 + 2 NUM_OUT operands do not fit the register
+// file, so they stay double-buffered: the next GEMM's operand is requested (L2) before the current GEMM runs
+template <int NUM_OUT, bool HOUT>
+__global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
+  __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int64_t n_tiles = (a.n_nodes + 31) / 32;
+  int64_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  constexpr int NOPS = 2 + 2 * NUM_OUT;
+  const float* ops[NOPS];
+  ops[0] = a.l2;
+  ops[1] = a.l3;
+#pragma unroll
+  for (int k = 0; k < NUM_OUT; ++k) {
+    ops[2 + k] = a.po[k];
+    ops[2 + NUM_OUT + k] = a.pot[NUM_OUT - 1 - k];
+  }
+  BFrag fb0, fb1;
+  auto gemm = [&](auto idx_c, const _Float16* t, bool more_tiles) -> f32x16 {
+    constexpr int idx = decltype(idx_c)::value;
+    BFrag& cur = (idx & 1) ? fb1 : fb0;
+    BFrag& nxt = (idx & 1) ? fb0 : fb1;
+    if constexpr (idx + 1 < NOPS) load_bfrag(nxt, ops[idx + 1], w, lane);
+    else if (more_tiles) load_bfrag(nxt, ops[0], w, lane);  // NOPS is even: nxt is fb0 again
+    if constexpr (HOUT && idx >= 2) return gemm_cols_half(t, cur, lane);
+    else return gemm_cols_frag(t, cur, lane);
+  };
+  auto put = [&](_Float16* t, f32x16& v) {  // the output network's activations
+    if (HOUT) cols_to_plane_half(t, v, w, lane);
+    else cols_to_planes(t, v, w, lane);
+  };
+  RowsPre pre;
+  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+  f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
+  load_bfrag(fb0, ops[0], w, lane);
+  const f32x16 b2 = load_cols(a.b2, 0, true, w, h), b3 = load_cols(a.b3, 0, true, w, h);
+  const bool col0 = w == 0 && h == 0;  // this lane's register 0 is column 0
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
+    const bool ok = row < a.n_nodes, more = next < n_tiles;
+    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+    const f32x16 x_old = xo;
+    if (more) {
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, next * 32, a.n_nodes, tid);
+      xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
+    }
+    __syncthreads();
+    f32x16 acc = gemm(std::integral_constant<int, 0>{}, bufX, more);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 t = tanh_fast2(f32x2{acc[r], acc[r + 1]} + f32x2{b2[r], b2[r + 1]});
+      acc[r] = t[0];
+      acc[r + 1] = t[1];
+    }
+    store_cols(a.t_out, row, ok, w, h, acc);
+    cols_to_planes(bufY, acc, w, lane);
+    __syncthreads();
+    acc = gemm(std::integral_constant<int, 1>{}, bufY, more);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ok ? x_old[r] + (acc[r] + b3[r]) : 0.f;
+    put(bufX, acc);
+    __syncthreads();
+    // ---- output network forward (tanh hidden layers, last layer linear without bias)
+    f32x16 hk[2];
+    _Float16* cur = bufX;
+    _Float16* nxt = bufY;
+    static_for<0, NUM_OUT - 1>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur, more);
+      const f32x16 bk = load_cols(a.bo[k], 0, true, w, h);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t = tanh_fast2(f32x2{hk[k][r], hk[k][r + 1]} + f32x2{bk[r], bk[r + 1]});
+        hk[k][r] = t[0];
+        hk[k][r + 1] = t[1];
+      }
+      put(nxt, hk[k]);  // W16A16: hk <- f16(tanh), what the backward multiplies by
+      __syncthreads();
+      _Float16* tmp = cur; cur = nxt; nxt = tmp;
+    });
+    const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur, more);
+    if (col0 && ok) a.e_node[row] = e[0];
+    // ---- output network backward: dE/de = 1 in column 0
+    f32x16 g = zero16();
+    if (col0) g[0] = 1.0f;
+    put(nxt, g);
+    __syncthreads();
+    { _Float16* tmp = cur; cur = nxt; nxt = tmp; }
+    static_for<0, NUM_OUT - 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;   // operand pot[NUM_OUT-1-j], multiplies by 1 - hk[NUM_OUT-2-j]^2
+      constexpr int k = NUM_OUT - 1 - j;
+      g = gemm(std::integral_constant<int, 2 + NUM_OUT + j>{}, cur, more);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
+      put(nxt, g);  // W16A16: f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
+      __syncthreads();
+      _Float16* tmp = cur; cur = nxt; nxt = tmp;
+    });
+    g = gemm(std::integral_constant<int, NOPS - 1>{}, cur, more);
+    store_cols(a.gx, row, ok, w, h, g);
+    __syncthreads();
+  }
+}
+
+// two workgroups (4 waves each) per molecule, each with half of its pair list: forces from dE/dd of the pairs,
+// energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered
+// inside one wave) and the four copies are added in fixed order; the two workgroups then add their halves to
+// the force array that pairs_kernel zeroed: two addends commute, so the result is reproducible.
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
                                                      const int64_t* __restrict__ mol_ptr,
                                                      const uint32_t* __restrict__ poi,
@@ -2534,7 +2713,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      float* __restrict__ energy,
                                                      float* __restrict__ forces, int max_beads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
   const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
   float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos
@@ -2542,10 +2721,12 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   for (int i = tid; i < 12 * n; i += 256) smem[i] = 0.f;
   __syncthreads();
   const int np = npairs[m];
+  const int np_half = ((np + 15) >> 4) << 3;  // the first workgroup's share (whole 8-entry segments)
+  const int q_lo = half ? min(np, np_half) : 0, q_hi = half ? np : min(np, np_half);
   // every thread walks a contiguous run of the (centre-sorted) list: the centre's contribution is
   // summed in registers and flushed when the centre changes, so lanes rarely collide in LDS
-  const int chunk = (np + 255) / 256;
-  const int p_lo = min(np, tid * chunk), p_hi = min(np, p_lo + chunk);
+  const int chunk = (q_hi - q_lo + 255) / 256;
+  const int p_lo = min(q_hi, q_lo + tid * chunk), p_hi = min(q_hi, p_lo + chunk);
   int ci = -1;
   float cx = 0.f, cy = 0.f, cz = 0.f;
   for (int p = p_lo; p < p_hi; ++p) {
@@ -2580,14 +2761,16 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     atomicAdd(&g[3 * ci + 1], cy);
     atomicAdd(&g[3 * ci + 2], cz);
   }
-  float e = 0.f;
-  for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
-  e = fmd_wave_sum(e);
-  if (lane == 0) esum[wv] = e;
+  if (half == 0) {
+    float e = 0.f;
+    for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
+    e = fmd_wave_sum(e);
+    if (lane == 0) esum[wv] = e;
+  }
   __syncthreads();
   for (int i = tid; i < 3 * n; i += 256)
-    forces[3 * a0 + i] = -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]);
-  if (tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
+    unsafeAtomicAdd(&forces[3 * a0 + i], -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]));
+  if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
 }
 
 void* g_stamp_buffer = nullptr;
@@ -2942,13 +3125,28 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
   auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
   if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
-  // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads)
-  const size_t lds_pairs =
+  // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads), then the entry staging
+  // area: as much of the worst-case list as fits in 128 KB (the list of a 1ENH-sized molecule takes 32 KB)
+  const size_t lds_pairs_base =
       (7 * max_beads_per_mol + 2 + 2 * ((max_beads_per_mol + 63) / 64) * max_beads_per_mol) * sizeof(float);
+  const size_t lds_pairs_max = 128 * 1024;
+  const size_t lds_pairs = lds_pairs_base + (size_t)cap * 4 < lds_pairs_max ? lds_pairs_base + (size_t)cap * 4 : lds_pairs_max;
+  const int ent_cap = (int)((lds_pairs - lds_pairs_base) / 4);
+  {
+    static std::atomic<int> pairs_attr[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FMD_ELAUNCH;
+    if (!pairs_attr[dev].load(std::memory_order_relaxed)) {
+      if (hipFuncSetAttribute((const void*)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_pairs_max) != hipSuccess)
+        return FMD_ELAUNCH;
+      pairs_attr[dev].store(1, std::memory_order_relaxed);
+    }
+  }
   ev_begin();
   pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
-                                                     ws.pc, ws.pdc, ws.npairs, status, (int)max_beads_per_mol);
+                                                     ws.pc, ws.pdc, ws.npairs, status, (int)max_beads_per_mol, forces, ent_cap);
   ev_end();
   FMD_CHECK_LAUNCH();
 
@@ -2983,6 +3181,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   if (const char* e = getenv("FMD_NODE_RES")) node_res = sp && atoi(e) != 0;
   const int64_t cus = device_cus();
   const unsigned res_grid = (unsigned)(n_tiles < cus ? n_tiles : cus);
+  int64_t og = cus;  // (one workgroup per CU is resident: the kernel needs most of the register file)
+  if (const char* e = getenv("FMD_OUT_GRID")) og = atoi(e) > 0 ? atoi(e) : og;
+  const unsigned out_grid = (unsigned)(n_tiles < og ? n_tiles : og);
   const int64_t slab_stride = n_nodes * F;
   dim3 egrid((unsigned)split, (unsigned)n_mol);
 
@@ -3045,11 +3246,15 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
     ev_begin();
     if (desc->num_out == 3) {
-      if (desc->precision == FMD_PREC_W16A16) node_out_kernel<3, true, true><<<node_grid, 256, 0, s>>>(oa);
+      if (node_res && desc->precision == FMD_PREC_W16A16) node_out_res_kernel<3, true><<<out_grid, 256, 0, s>>>(oa);
+      else if (node_res) node_out_res_kernel<3, false><<<out_grid, 256, 0, s>>>(oa);
+      else if (desc->precision == FMD_PREC_W16A16) node_out_kernel<3, true, true><<<node_grid, 256, 0, s>>>(oa);
       else if (sp) node_out_kernel<3, true, false><<<node_grid, 256, 0, s>>>(oa);
       else node_out_kernel<3, false, false><<<node_grid, 256, 0, s>>>(oa);
     } else {
-      if (desc->precision == FMD_PREC_W16A16) node_out_kernel<2, true, true><<<node_grid, 256, 0, s>>>(oa);
+      if (node_res && desc->precision == FMD_PREC_W16A16) node_out_res_kernel<2, true><<<out_grid, 256, 0, s>>>(oa);
+      else if (node_res) node_out_res_kernel<2, false><<<out_grid, 256, 0, s>>>(oa);
+      else if (desc->precision == FMD_PREC_W16A16) node_out_kernel<2, true, true><<<node_grid, 256, 0, s>>>(oa);
       else if (sp) node_out_kernel<2, true, false><<<node_grid, 256, 0, s>>>(oa);
       else node_out_kernel<2, false, false><<<node_grid, 256, 0, s>>>(oa);
     }
@@ -3082,7 +3287,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     if (rc != FMD_OK) return rc;
   }
   ev_begin();
-  finish_kernel<<<(unsigned)n_mol, 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
+  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
       pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, fs ? ws.pgd + n_mol * cap : nullptr, ws.npairs, (int)cap,
       ws.e_node, energy, forces, (int)max_beads_per_mol);
   ev_end();
