@@ -475,7 +475,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin): the row's
   // candidates j > i are tested 64 at a time, the ballots are kept as hit masks in LDS and drive the fill.
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t a0 = mol_ptr[m];
   int n = (int)(mol_ptr[m + 1] - a0);
   if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 1) void edge_fwd_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hid = smem;                 // [32][LDA]
   float* agg = smem + TILE_FLOATS;   // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   int m, split;
   wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_ws_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hid = smem;                 // [32][LDA]
   float* agg = smem + TILE_FLOATS;   // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
   int m, split;
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
   float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
   float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
   int m, split;
@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   // Wc = W0 diag(centre - c0) on the same fragments (W0 (raw (d - centre)) = (d - c0) W0 raw - Wc raw).
   float* frag_l = b0_l + 128;                                    // [nb][2][32] x 16 B   (SHARE only)
   float* gx1 = frag_l + (SHARE ? a.nb * 256 : 0);                // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
   int m, split;
@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(256, 1) void edge_bwd_kernel(EdgeArgs a) {
   float* buf = smem;                       // [32][LDA]: hidden tile, then gW tile
   float* red = smem + TILE_FLOATS;         // [4][32]
   float* gx1 = smem + TILE_FLOATS + 128;   // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c32 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   int m, split;
   wg_to_mol_split(m, split);
   const int64_t a0 = a.mol_ptr[m];
@@ -2104,7 +2104,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256) void node_fwd_kernel(NodeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const int col = 32 * w + (lane & 31);
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -2167,7 +2167,7 @@ template <int NUM_OUT, bool SPLIT, bool HOUT>
 __global__ __launch_bounds__(256) void node_out_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const int col = 32 * w + (lane & 31);
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   // the 2 + 2 NUM_OUT GEMMs of a tile, in order: lin2, lin, output net forward, output net backward
@@ -2293,7 +2293,7 @@ template <bool HAS_SLABS, bool SPLIT>
 __global__ __launch_bounds__(256) void node_bwd_kernel(NodeBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float bufA[TILE_FLOATS];
   __shared__ __attribute__((aligned(16))) float bufB[TILE_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
   const int col = 32 * w + (lane & 31);
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -2461,7 +2461,7 @@ __global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufZ[2 * NPLANE];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, nl = lane & 31;
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -2511,7 +2511,7 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufZ[2 * NPLANE];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, nl = lane & 31;
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -2597,7 +2597,7 @@ template <int NUM_OUT, bool HOUT>
 __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, nl = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, nl = lane & 31;
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
@@ -2713,7 +2713,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      float* __restrict__ energy,
                                                      float* __restrict__ forces, int max_beads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t a0 = mol_ptr[m];
   const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
   float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos

@@ -18,9 +18,9 @@ import json
 import os
 import sys
 
-ENGINE = ["pairs_kernel", "node_fwd_kernel", "edge_fwd", "node_out_kernel", "node_bwd_kernel", "edge_bwd",
-          "finish_kernel"]
-NAMES = {"edge_fwd": "edge_fwd_kernel", "edge_bwd": "edge_bwd_kernel"}
+ENGINE = ["pairs_kernel", "node_embed", "node_fwd", "edge_fwd", "node_out", "node_bwd", "edge_bwd", "finish_kernel"]
+NAMES = {"edge_fwd": "edge_fwd_kernel", "edge_bwd": "edge_bwd_kernel", "node_embed": "node_embed_kernel",
+         "node_fwd": "node_fwd_kernel", "node_out": "node_out_kernel", "node_bwd": "node_bwd_kernel"}
 
 
 def collect(d, counter):
