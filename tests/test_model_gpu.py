@@ -452,3 +452,29 @@ def test_fused_engine_random_ragged_batches(params):
     re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
     print(f"40 random ragged molecules: energy {re:.2e} forces {rf:.2e}, pairs {int(eng.status[2])}")
     assert re < 1e-4 and rf < 1e-4
+
+
+@pytest.mark.parametrize("n_beads", [269, 300])
+def test_fused_engine_dense_molecules(params, n_beads):
+    """Every bead inside every other bead's cutoff (a ball of radius 2.4 at cutoff 5): the pair list is the
+    complete graph, 36k / 45k entries per molecule -- longer than the LDS staging area of pairs_kernel, so its
+    direct-to-HBM fill runs (269: the normal mode, 300: the feature-split mode) -- and runs end on every residue
+    mod 4, so the padding rules see all cases.  Parity with the fp64 oracle, pair count, reproducibility."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(77 + n_beads)
+    B = 3
+    x = torch.randn(B * n_beads, 3, generator=g)
+    x = x / x.norm(dim=1, keepdim=True) * 2.4 * torch.rand(B * n_beads, 1, generator=g) ** (1 / 3)
+    ptr = torch.arange(B + 1, dtype=torch.int64) * n_beads
+    types = torch.randint(1, 20, (B * n_beads,), generator=g)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), x.double(), types, ptr)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e, f = eng.energy_forces(x.to(DEV), types.to(DEV), ptr.to(DEV), n_beads)
+    assert int(eng.status[0]) == 0 and int(eng.status[2]) == B * n_beads * (n_beads - 1) // 2
+    e2, f2 = eng.energy_forces(x.to(DEV), types.to(DEV), ptr.to(DEV), n_beads)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    print(f"dense {n_beads}-bead molecules: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4
