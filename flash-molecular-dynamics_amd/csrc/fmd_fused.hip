@@ -472,10 +472,12 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ status, int max_beads, float* __restrict__ forces, int ent_cap) {
-  // One workgroup (16 waves) per molecule, one wave per centre row (rows dealt round-robin): the row's
-  // candidates j > i are tested 64 at a time, the ballots are kept as hit masks in LDS and drive the fill.
+  // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
+  // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
+  // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t a0 = mol_ptr[m];
   int n = (int)(mol_ptr[m + 1] - a0);
   if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
@@ -492,14 +494,15 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   const int NC = (n + 63) >> 6;                 // 64-candidate chunks of a row (at most 9: 535 beads)
   // [n][NC] hit masks: bit b of masks[i NC + c] <-> (i, 64 c + b) is a pair; chunks below (i + 1) / 64 are not written
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((7 * n + 2) & ~1));
-  __shared__ int tot_s[2];
+  __shared__ int tot_s[3];
   for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
     sz[i] = pos[3 * (a0 + i) + 2];
   }
   // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
-  for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
+  if (part == 0)
+    for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
   __syncthreads();
   auto dist2 = [&](int i, int j) {
     const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
@@ -648,6 +651,22 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
   __syncthreads();
   const int total = tot_s[0];
+  // this workgroup's rows [r_lo, r_hi) and entries [k_lo, k_hi): the split row is the first one that starts in the
+  // second half of the list (row offsets ascend)
+  if (tid < 64) {
+    int below = 0;
+    for (int i = tid; i < n; i += 64) below += rowstart[i] < (total >> 1) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+    if (tid == 0) tot_s[2] = below;
+  }
+  __syncthreads();
+  const int r_split = tot_s[2];
+  int r_next = r_split;  // the first non-empty row of the second part: its (final) offset ends the first part's pads
+  while (r_next < n && cnt[r_next] == 0) ++r_next;
+  const int k_split = r_next < n ? rowstart[r_next] : total;
+  const int r_lo = part ? r_split : 0, r_hi = part ? n : r_split;
+  const int k_lo = part ? k_split : 0, k_hi = part ? total : k_split;
   // ---- pass 2: fill from the masks (sorted by j)
   uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
   uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
@@ -659,7 +678,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   // densely, by the pass below.  A longer list is written straight to the arrays and read back.
   uint32_t* ent = reinterpret_cast<uint32_t*>(masks + n * NC);
   const bool staged = total <= ent_cap;
-  for (int i = wv; i < n; i += 16) {
+  for (int i = r_lo + wv; i < r_hi; i += 16) {
     if (cnt[i] == 0) continue;
     int k = rowstart[i];
     k = __builtin_amdgcn_readfirstlane(k);
@@ -695,7 +714,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   __syncthreads();  // (workgroup-scope release/acquire of the entries written above)
   // ---- distances and cutoff values, one entry per lane (in a candidate sweep only one lane in five holds a pair,
   //      so sqrt / sin / cos there would run at a fifth of the lanes)
-  for (int k = tid; k < min(total, cap); k += 1024) {
+  for (int k = k_lo + tid; k < min(k_hi, cap); k += 1024) {
     int i, j;
     if (staged) {
       const uint32_t e = ent[k];
@@ -718,7 +737,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
   // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
   // need a validity test
-  {
+  if (part == 1) {
     const int tot_c = min(total, cap) & ~7;
     const int tot32 = min((tot_c + 31) & ~31, cap);
     for (int k = tot_c + tid; k < tot32; k += 1024) {
@@ -729,7 +748,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       dc_out[k] = 0.f;
     }
   }
-  if (tid == 0) {
+  if (part == 0 && tid == 0) {
     const int real = tot_s[1];
     npairs[m] = min(total, cap) & ~7;
     if (total > cap) status[0] = FMD_ECAPACITY;
@@ -3144,7 +3163,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     }
   }
   ev_begin();
-  pairs_kernel<<<(unsigned)n_mol, 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
+  pairs_kernel<<<dim3(2, (unsigned)n_mol), 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
                                                      ws.pc, ws.pdc, ws.npairs, status, (int)max_beads_per_mol, forces, ent_cap);
   ev_end();
