@@ -471,7 +471,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
-                                                    int32_t* __restrict__ status, int max_beads, float* __restrict__ forces, int ent_cap) {
+                                                    int32_t* __restrict__ report, int max_beads, float* __restrict__ forces, int ent_cap) {
   // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
   // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
   // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
@@ -481,9 +481,9 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   const int64_t a0 = mol_ptr[m];
   int n = (int)(mol_ptr[m + 1] - a0);
   if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
-    if (threadIdx.x == 0) status[0] = FMD_EINVAL;
     n = max_beads;
   }
+  const bool bad_bound = (int)(mol_ptr[m + 1] - a0) > max_beads;
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
@@ -748,12 +748,13 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       dc_out[k] = 0.f;
     }
   }
+  // per-molecule report (error code, entries needed, real pairs): finish_kernel reduces it into the status words,
+  // so nothing has to be zeroed before the call
   if (part == 0 && tid == 0) {
-    const int real = tot_s[1];
     npairs[m] = min(total, cap) & ~7;
-    if (total > cap) status[0] = FMD_ECAPACITY;
-    atomicMax(&status[1], total);
-    atomicAdd(&status[2], real);
+    report[3 * m] = bad_bound ? FMD_EINVAL : (total > cap ? FMD_ECAPACITY : 0);
+    report[3 * m + 1] = total;
+    report[3 * m + 2] = tot_s[1];
   }
 }
 
@@ -2730,7 +2731,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ npairs, int cap,
                                                      const float* __restrict__ e_node,
                                                      float* __restrict__ energy,
-                                                     float* __restrict__ forces, int max_beads) {
+                                                     float* __restrict__ forces, int max_beads,
+                                                     const int32_t* __restrict__ report,
+                                                     int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t a0 = mol_ptr[m];
@@ -2790,6 +2793,30 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   for (int i = tid; i < 3 * n; i += 256)
     unsafeAtomicAdd(&forces[3 * a0 + i], -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]));
   if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
+  // the call's status words from pairs_kernel's per-molecule reports (one wave of the first workgroup; a bead-bound
+  // violation outranks a capacity overflow)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) {
+    int err = 0, need = 0, real = 0;
+    for (int q = lane; q < (int)gridDim.y; q += 64) {
+      const int e = report[3 * q];
+      err = (e == FMD_EINVAL || err == FMD_EINVAL) ? FMD_EINVAL : (e != 0 ? e : err);
+      need = max(need, report[3 * q + 1]);
+      real += report[3 * q + 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int e = __shfl_xor(err, o, 64);
+      err = (e == FMD_EINVAL || err == FMD_EINVAL) ? FMD_EINVAL : (e != 0 ? e : err);
+      need = max(need, __shfl_xor(need, o, 64));
+      real += __shfl_xor(real, o, 64);
+    }
+    if (lane == 0) {
+      status[0] = err;
+      status[1] = need;
+      status[2] = real;
+      status[3] = 0;
+    }
+  }
 }
 
 void* g_stamp_buffer = nullptr;
@@ -2804,6 +2831,7 @@ struct Workspace {
   float* slabs;
   uint32_t *poi, *poj;
   int32_t* npairs;
+  int32_t* report;  // [n_mol][3] pairs_kernel -> finish_kernel
   int64_t total;
 };
 
@@ -2852,6 +2880,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   w.pdc = (float*)take(n_mol * cap * 4);
   w.pgd = (float*)take(2 * n_mol * cap * 4);  // second slab: feature-split mode
   w.npairs = (int32_t*)take(n_mol * 4);
+  w.report = (int32_t*)take(n_mol * 12);
   w.total = p - reinterpret_cast<char*>(base);
   return w;
 }
@@ -3143,7 +3172,6 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   // a NULL slot skips that record: a caller may time a single kernel without paying for 2 records per launch
   auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
   auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
-  if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), s) != hipSuccess) return FMD_ELAUNCH;
   // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads), then the entry staging
   // area: as much of the worst-case list as fits in 128 KB (the list of a 1ENH-sized molecule takes 32 KB)
   const size_t lds_pairs_base =
@@ -3165,7 +3193,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   ev_begin();
   pairs_kernel<<<dim3(2, (unsigned)n_mol), 1024, lds_pairs, s>>>(pos, mol_ptr, desc->cutoff * desc->cutoff,
                                                      desc->cutoff, (int)cap, ws.poi, ws.poj, ws.pd,
-                                                     ws.pc, ws.pdc, ws.npairs, status, (int)max_beads_per_mol, forces, ent_cap);
+                                                     ws.pc, ws.pdc, ws.npairs, ws.report, (int)max_beads_per_mol, forces, ent_cap);
   ev_end();
   FMD_CHECK_LAUNCH();
 
@@ -3308,7 +3336,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   ev_begin();
   finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * max_beads_per_mol * sizeof(float), s>>>(
       pos, mol_ptr, ws.poi, ws.poj, ws.pd, ws.pgd, fs ? ws.pgd + n_mol * cap : nullptr, ws.npairs, (int)cap,
-      ws.e_node, energy, forces, (int)max_beads_per_mol);
+      ws.e_node, energy, forces, (int)max_beads_per_mol, ws.report, status);
   ev_end();
   FMD_CHECK_LAUNCH();
   return FMD_OK;
