@@ -478,3 +478,19 @@ def test_fused_engine_dense_molecules(params, n_beads):
     re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
     print(f"dense {n_beads}-bead molecules: energy {re:.2e} forces {rf:.2e}")
     assert re < 1e-4 and rf < 1e-4
+
+
+def test_fused_engine_empty_molecule_in_batch(params):
+    """A molecule with no beads between two normal ones (mol_ptr repeats an offset): its energy is 0, the others are
+    untouched."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(2, 40, 5.0)
+    ptr3 = torch.tensor([0, 40, 40, 80], dtype=torch.int64)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    e3, f3 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr3.to(DEV), 40)
+    assert int(eng.status[0]) == 0
+    assert float(e3[1]) == 0.0
+    assert torch.equal(e3[[0, 2]], e2) and torch.equal(f3, f2)
