@@ -203,12 +203,14 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
 /* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY (pair list too small) / FMD_EINVAL (a molecule has more
  * beads than max_beads_per_mol: it was truncated to stay inside the LDS sized for that bound -- results are
  * meaningless), [1] = max pairs seen in one molecule,
- * [2] = total pairs, [3] reserved. Read it back at the caller's convenience. */
+ * [2] = total pairs, [3] reserved (0). All four words are written by the call's last kernel (nothing has to be
+ * zeroed beforehand); read them back at the caller's convenience.  forces / energy are fully overwritten. */
 /* max_beads_per_mol: upper bound on beads of one molecule.  The per-molecule aggregate lives in LDS: up to 283
  * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each;
  * FMD_PREC_F32 and FMD_PREC_W16A16 only).  Larger molecules return FMD_EUNSUPPORTED and take the operator path.
  * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
- *   multiples of 8 entries; A(A-1)/2 + 8A can never overflow.
+ *   multiples of 4 entries (plus at most one 4-entry group per run and 7 at the end); A(A-1)/2 + 8A can never
+ *   overflow.
  * workspace: fmd_schnet_workspace_bytes bytes, 256-byte aligned. */
 int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
                              const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
