@@ -494,3 +494,22 @@ def test_fused_engine_empty_molecule_in_batch(params):
     assert int(eng.status[0]) == 0
     assert float(e3[1]) == 0.0
     assert torch.equal(e3[[0, 2]], e2) and torch.equal(f3, f2)
+
+
+@pytest.mark.parametrize("knob", ["FMD_NODE_RES", "FMD_EDGE_BWD_SHARE", "FMD_EDGE_FWD_SHARE"])
+def test_fused_engine_alternative_kernels(params, knob, monkeypatch):
+    """The kernel variants the experiment knobs select (streamed node kernels, per-wave Gaussians in the pair
+    kernels) stay correct: same results as the default kernels up to summation order, parity with the fp64 oracle."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(6, 120, 5.0)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e_d, f_d = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    monkeypatch.setenv(knob, "0")
+    e_a, f_a = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
+    monkeypatch.delenv(knob)
+    assert float((f_a - f_d).norm() / f_d.norm()) < 1e-5
+    re, rf = _relerr(e_a, f_a, e_o.numpy(), f_o.numpy())
+    assert re < 1e-4 and rf < 1e-4
