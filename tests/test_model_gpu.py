@@ -51,23 +51,41 @@ def test_operator_path_vs_reference_vectors(params, golden_dir, case):
     assert re < 2e-5 and rf < 2e-5  # where fp32 actually lands
 
 
-def test_operator_path_w16a16_vs_w16a16_oracle(params, golden_dir):
-    """BASELINE config 3.  The W16A16 oracle restates the reference's rounding points (SURVEY A9);
-    the reference's fp16 Triton path cannot run in the build container, so this config is
-    'parity unpinned' beyond that restatement.  Tolerance 2e-3 on forces (fp16 storage: the order of
-    fp32 accumulation moves results across fp16 rounding boundaries), and the deviation from the
-    fp32 reference is reported."""
+def _w16_reference(golden_dir, case):
+    """The reference's own W16A16 energies/forces (oracle/make_golden_triton.py: its GPTQ modules and Triton
+    kernels K4-K7 executed under TRITON_INTERPRET=1) and the spread between two of its listed autotune
+    configurations -- fp16 storage roundings flip when only the association of fp32 partial sums changes."""
+    r = np.load(os.path.join(golden_dir, "case_w16a16_ref.npz"))
+    ea, eb, fa, fb = (r[case + k] for k in ("_energy", "_energy_cfgB", "_forces", "_forces_cfgB"))
+    spread_f = float(np.linalg.norm(fa.astype(np.float64) - fb) / np.linalg.norm(fa))
+    spread_e = float(np.abs(ea.astype(np.float64) - eb).max() / np.abs(ea).max())
+    return (ea, fa), (eb, fb), spread_e, spread_f
+
+
+def _w16_check(tag, e, f, golden_dir, case):
+    """Tolerance from the data: 3 x the reference's own configuration-to-configuration spread (forces
+    3.5-4.0e-4 => ~1.1e-3; energies: the spread of the case, floor 5e-4)."""
+    (ea, fa), (eb, fb), spread_e, spread_f = _w16_reference(golden_dir, case)
+    ra, rb = _relerr(e, f, ea, fa), _relerr(e, f, eb, fb)
+    re, rf = min(ra[0], rb[0]), min(ra[1], rb[1])
+    print(f"{case} {tag}: vs reference W16A16 energy {re:.2e} forces {rf:.2e} "
+          f"(reference's own spread: energy {spread_e:.2e} forces {spread_f:.2e})")
+    assert rf < 3 * spread_f
+    assert re < max(3 * spread_e, 5e-4)
+
+
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
+def test_operator_path_w16a16_vs_reference_w16a16(params, golden_dir, case):
+    """BASELINE config 3, operator path (the reference's rounding points one by one) against the reference's
+    own W16A16 result."""
     import flashmd_amd.schnet as S
 
-    z = np.load(os.path.join(golden_dir, "case_small_3x37.npz"))
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
     pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
     e, f = _run(S, params, pos, types, ptr, engine=False, w16a16=True)
-    e_o, f_o = so.schnet_energy_forces(params, pos, types, ptr, w16a16=True)
-    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    _w16_check("operator path", e, f, golden_dir, case)
     re32, rf32 = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
-    print(f"w16a16: vs w16a16 oracle energy {re:.2e} forces {rf:.2e}; vs fp64 reference {re32:.2e} {rf32:.2e}")
-    assert re < 2e-3 and rf < 2e-3
-    assert rf32 < 5e-2
+    assert rf32 < 5e-3  # the reference's W16A16 itself sits 9e-4 from its fp64 result
 
 
 def test_operator_path_deterministic_csr(params):
@@ -197,13 +215,13 @@ def test_nve_velocity_verlet_conserves_energy(params):
     assert spread[1] < 0.8 * spread[0]
 
 
-@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269"])
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
 def test_fused_engine_w16a16(params, golden_dir, case):
     """BASELINE config 3 on the fused engine (precision="w16a16"): fp16 operands / fp32 accumulation in the
     filter and output networks.  The engine differentiates in forward mode and folds the cutoff into the
-    hidden tile, so its fp16 rounding points are not the reference's one by one: it is held to the same
-    2e-3 band around the W16A16 oracle as the operator path ('parity unpinned' beyond the restatement),
-    and its distance to the fp32 reference is reported beside the oracle's own."""
+    hidden tile, so its fp16 rounding points are not the reference's one by one; it is held to the same band
+    around the reference's own W16A16 vectors as the operator path (3 x the reference's configuration-to-
+    configuration spread)."""
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
@@ -212,13 +230,8 @@ def test_fused_engine_w16a16(params, golden_dir, case):
     model = S.model_from_params(params).to(DEV)
     eng = engine.FusedSchNetEngine(model, precision="w16a16")
     e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
-    e_o, f_o = so.schnet_energy_forces(params, pos, types, ptr, w16a16=True)
-    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    _w16_check("fused engine", e, f, golden_dir, case)
     re32, rf32 = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
-    ro = _relerr(e_o, f_o, z["energy_ref64"], z["forces_ref64"])
-    print(f"{case} w16a16 engine: vs w16a16 oracle energy {re:.2e} forces {rf:.2e}; vs fp64 reference "
-          f"{re32:.2e} {rf32:.2e} (oracle itself {ro[0]:.2e} {ro[1]:.2e})")
-    assert re < 2e-3 and rf < 2e-3
     assert rf32 < 5e-3
     e2, f2 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
     assert torch.equal(f, f2) and torch.equal(e, e2)
