@@ -12,4 +12,4 @@ extern "C" const char* fmd_strerror(int code) {
   }
 }
 
-extern "C" int fmd_abi_version(void) { return 1; }
+extern "C" int fmd_abi_version(void) { return 2; }

@@ -1,0 +1,316 @@
+// Internal header of the fused CGSchNet engine (fmd_engine_*.hip): sizes, kernel argument records, the launchers each
+// translation unit exports to the host side (fmd_engine_host.hip), and the device helpers the kernels share.
+// Nothing here is part of the C ABI (include/flashmd_hip.h).
+//
+// Design (MI355X first):
+//  * the radius graph is symmetric and the filter W_ij = filt(d_ij) * C(d_ij) depends on the pair
+//    only, so work is organised over UNDIRECTED pairs i<j: the filter network runs once per pair and
+//    feeds both directions (half the MFMA work of a per-edge formulation, same arithmetic);
+//  * one workgroup owns a share of one molecule's pair tiles (32 pairs) and keeps the molecule's
+//    aggregate (<= 283 beads x 128 features, fp32) in LDS until one final flush; 8 waves, specialised:
+//    producers (rbf, filter layer 0, tanh -> hidden tile in LDS) and consumers (filter layer 1, row
+//    gathers, aggregate update), each owning a 32-feature slice whose weight fragments live in VGPRs.
+//    Every aggregate element is touched by exactly one wave in program order => bit-reproducible sums;
+//  * contractions: precision FMD_PREC_F32 = split-operand f16 MFMA (x = hi + lo/2048, three products,
+//    fp32 accumulation, 2e-7 = the error of the fp32 MFMA at 3/16 of its cycles); FMD_PREC_W16A16 = one
+//    product of fp16-rounded operands;
+//  * backward recomputes the filter instead of storing [E,F] tensors, and gets d/d(distance) from
+//    the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice GEMMs), so the only
+//    per-pair quantity that reaches HBM is one float (dE/dd) per pair.
+#pragma once
+#include <string.h>
+#include <type_traits>
+
+#include "fmd_common.h"
+
+namespace fmd_eng {
+
+constexpr int F = 128;            // hidden = filters
+constexpr int LDA = 132;          // floats per row of the tile region (its size is kept: 32 x 132 floats)
+constexpr int TILE_FLOATS = 32 * LDA;
+constexpr size_t MAX_LDS_BYTES = 160 * 1024;
+constexpr int MAX_LDS_ROWS = 283; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
+constexpr int MAX_LDS_ROWS_FS = 535;  // ... in feature-split mode (64 features per workgroup, any num_rbf)
+constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // split operand, K padded to 64: [wave][k-step of 16][lane] x 8 halves (16 B)
+constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
+constexpr int SLICE = 2 * Q1_FLOATS;        // floats of one packed 128x128 node operand: hi record, lo record
+
+struct EdgeArgs {
+  const uint32_t* poi;     // centre row byte offsets (i * 512)
+  const uint32_t* poj;     // neighbour row byte offsets (j * 512)
+  const float* pd;
+  const float* pc;         // C(d) per pair
+  const float* pdc;        // C'(d) per pair
+  float* pgd;              // dE/dd per pair (backward)
+  int64_t pgd_stride;      // FS mode: second dE/dd slab at pgd + pgd_stride
+  bool fs;                 // feature-split mode (host dispatch only)
+  const int32_t* npairs;
+  const int64_t* mol_ptr;
+  const float* x1;         // [N,128] of this block
+  const float* gagg;       // [N,128] dE/d(agg) (backward)
+  const float* b0;
+  const float *q0h, *q0l, *q1h, *q1l, *q1th, *q1tl;  // fp16 hi/lo split operands (16-byte records)
+  const float *q0ch, *q0cl;                          // centre-weighted W0 (backward, shared-Gaussian form)
+  float c0;                                          // cutoff / 2
+  int nb;                                            // ceil(num_rbf / 8): half k-steps that hold Gaussians
+  const float* centers;    // [64]
+  float* slabs;            // [n_split][N,128] partial aggregates (fwd: agg, bwd: gx1)
+  int64_t slab_stride;
+  float gamma, rc;
+  int cap, n_split;
+  int max_beads;           // the caller's bound on beads per molecule: what the dynamic LDS was sized for
+};
+
+
+struct NodeFwdArgs {
+  float* x;            // [N,128] in/out
+  const float* slabs;  // agg partials of the previous block
+  int64_t slab_stride;
+  int n_slabs;
+  const float *l2, *b2, *l3, *b3;  // previous block's lin2 / lin
+  float* t_out;        // tanh(conv) of the previous block (kept for backward)
+  const float* l1;     // this block's lin1
+  float* x1_out;
+  int64_t n_nodes;
+};
+
+struct NodeOutArgs {
+  float* x;
+  const float* slabs;
+  int64_t slab_stride;
+  int n_slabs;
+  const float *l2, *b2, *l3, *b3;
+  float* t_out;
+  const float* po[3];   // packed output linears
+  const float* bo[3];   // biases (zero-filled when absent)
+  const float* pot[3];  // packed transposes
+  float* e_node;        // [N]
+  float* gx;            // [N,128] dE/dx_L
+  int64_t n_nodes;
+};
+
+struct NodeBwdArgs {
+  float* gx;             // [N,128] dE/dx_{l+1} in, dE/dx_l... (updated when slabs are given)
+  const float* slabs;    // gx1 partials of block l+1
+  int64_t slab_stride;
+  int n_slabs;
+  const float* l1t;      // lin1 of block l+1, transposed operand
+  const float* t;        // tanh(conv) of block l
+  const float *l3t, *l2t;
+  float* gagg;           // [N,128] out
+  int64_t n_nodes;
+};
+
+
+struct PairsArgs {
+  const float* pos;
+  const int64_t* mol_ptr;
+  float rc;
+  int cap;                 // pair-list capacity per molecule (multiple of 32)
+  uint32_t *poi, *poj;
+  float *pd, *pc, *pdc;
+  int32_t* npairs;
+  int32_t* report;         // [n_mol][3] pairs_kernel -> finish_kernel
+  int max_beads;
+  float* forces;           // zeroed here, accumulated by finish
+};
+struct FinishArgs {
+  const float* pos;
+  const int64_t* mol_ptr;
+  const uint32_t *poi, *poj;
+  const float* pd;
+  const float* pgd;
+  const float* pgd2;       // feature-split mode: second dE/dd slab, else null
+  const int32_t* npairs;
+  int cap;
+  const float* e_node;
+  float* energy;
+  float* forces;
+  int max_beads;
+  const int32_t* report;
+  int32_t* status;
+};
+
+// launchers (each returns FMD_OK / FMD_ELAUNCH / FMD_EUNSUPPORTED); setup_* raise the kernels' dynamic-LDS ceiling
+// once per device
+int setup_pairs_attrs();
+int setup_edge_fwd_attrs();
+int setup_edge_bwd_attrs();
+int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s);
+int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s);
+int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s);
+int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol, hipStream_t s);
+int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x1, float* x, float* x1,
+                      int64_t n_nodes, hipStream_t s);
+int launch_node_fwd(const NodeFwdArgs& a, unsigned grid, hipStream_t s);
+int launch_node_out(const NodeOutArgs& a, int num_out, bool hout, unsigned grid, hipStream_t s);
+int launch_node_bwd(const NodeBwdArgs& a, bool has_slabs, unsigned grid, hipStream_t s);
+
+}  // namespace fmd_eng
+
+namespace {
+using namespace fmd_eng;
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time unrolled loop: the body receives std::integral_constant<int, I> (true constants keep
+// every register-array index static, so nothing is demoted to scratch)
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int LDH = 136;                       // halves per row of an fp16 LDS tile (272 B)
+constexpr int TILE_H_BYTES = 32 * LDH * 2;     // one fp16 tile
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+
+// ---- packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two values per VALU slot):
+// the producers of the split pair kernels are VALU-issue bound, so their arithmetic is written on pairs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) {
+  return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+}
+// tanh = 1 - 2 rcp(e^{2x} + 1) on a pair (see fmd_tanh_fast)
+__device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
+  const f32x2 e = exp2_2(x * splat2(2.0f * LOG2E)) + splat2(1.0f);
+  const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return splat2(1.0f) - splat2(2.0f) * rc;
+}
+// W16A16 forms (template flag HALF): operands are rounded to fp16 once (round to nearest even, as the
+// reference's .half()) and a product is the single hi.hi MFMA; the lo words/tiles/fragments are unused.
+template <bool HALF>
+__device__ __forceinline__ void mfma_prod(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                          f32x16& acc1, f32x16& acc2);
+template <bool HALF>
+__device__ __forceinline__ f32x2 comb2(const f32x16& a1, const f32x16& a2, int r) {
+  if (HALF) return f32x2{a1[r], a1[r + 1]};
+  return f32x2{a1[r], a1[r + 1]} + f32x2{a2[r], a2[r + 1]} * f32x2{1.0f / 2048.0f, 1.0f / 2048.0f};
+}
+__device__ __forceinline__ uint32_t half_pair(f32x2 x) {  // v_cvt_pk_f16_f32 (RTE)
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  uint32_t u;
+  __builtin_memcpy(&u, &h, 4);
+  return u;
+}
+// one pair -> packed hi (2 halves) and lo (2 halves) words
+__device__ __forceinline__ void split_pair(f32x2 x, uint32_t& hi, uint32_t& lo) {
+  const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+  const f32x2 xs = x * splat2(SPLIT_SCALE);  // (x - h) 2048 as x 2048 - h 2048: v_fma_mix reads the half directly
+  const hv2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -SPLIT_SCALE, xs[0]),
+                                           __builtin_fmaf((float)h[1], -SPLIT_SCALE, xs[1]));
+  __builtin_memcpy(&hi, &h, 4);
+  __builtin_memcpy(&lo, &l, 4);
+}
+// raw Gaussians of one k-step (8 centres of this lane half) as split fragments; with WITH_DIFF also
+// raw * (d - centre), the operand of z' = W0 . d(rbf)/dd.  gl = gamma * log2(e).
+template <bool WITH_DIFF, bool HALF = false>
+__device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0, const f32x4& c1, f16x8& bh,
+                                              f16x8& bl, f16x8& ph, f16x8& pl) {
+  uint32_t xh[4], xl[4], qh[4], ql[4];
+  const f32x2 cc[4] = {f32x2{c0[0], c0[1]}, f32x2{c0[2], c0[3]}, f32x2{c1[0], c1[1]}, f32x2{c1[2], c1[3]}};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 diff = splat2(d) - cc[j];
+    const f32x2 raw = exp2_2((diff * diff) * splat2(gl));
+    if (HALF) {
+      xh[j] = half_pair(raw);
+      xl[j] = 0;
+      if (WITH_DIFF) { qh[j] = half_pair(raw * diff); ql[j] = 0; }
+    } else {
+      split_pair(raw, xh[j], xl[j]);
+      if (WITH_DIFF) split_pair(raw * diff, qh[j], ql[j]);
+    }
+  }
+  __builtin_memcpy(&bh, xh, 16);
+  __builtin_memcpy(&bl, xl, 16);
+  if (WITH_DIFF) {
+    __builtin_memcpy(&ph, qh, 16);
+    __builtin_memcpy(&pl, ql, 16);
+  }
+}
+
+template <bool HALF>
+__device__ __forceinline__ void mfma_prod(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                          f32x16& acc1, f32x16& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+  if (!HALF) {
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+  }
+}
+// acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
+__device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
+                                           const f16x8& bl, f32x16& acc1, f32x16& acc2) {
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
+  acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
+}
+
+
+// The same GEMM with the operand's fragments already in registers: lets a kernel that chains several GEMMs per
+// tile issue the NEXT operand's loads (L2, ~1-2 us) before it runs the current one.
+struct BFrag {
+  f16x8 h[8], l[8];
+};
+__device__ __forceinline__ void load_bfrag(BFrag& b, const float* pk, int w, int lane) {
+  asm volatile("" : "+s"(pk));  // the loads stay where they are written (not hoisted out of the tile loop)
+  const f16x8* bh = reinterpret_cast<const f16x8*>(pk) + (int64_t)w * 8 * 64 + lane;
+  const f16x8* bl = reinterpret_cast<const f16x8*>(pk + Q1_FLOATS) + (int64_t)w * 8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    b.h[s] = bh[s * 64];
+    b.l[s] = bl[s * 64];
+  }
+}
+
+// Centre-row sum of a segment.  A 32-entry tile is four 8-entry segments; the lower and the upper lane half hold
+// four entries each (register r = 4q + e <-> entry 8q + 4h + e).  Usually both halves belong to one centre and the
+// centre row gets the sum over all eight entries (both halves then store the same value to the same address).  Where
+// a centre's run ends on a 4-entry boundary the other half may belong to the next centre: pairs_kernel only pairs
+// them when (centre, neighbours) of the two halves are disjoint, and each half then keeps its own sum.
+__device__ __forceinline__ float fmd_segment_sum(float si, uint32_t centre_off) {
+  const auto c = __builtin_amdgcn_permlane32_swap(centre_off, centre_off, false, false);
+  const unsigned u = __builtin_bit_cast(unsigned, si);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float both = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+  return (unsigned)c[0] == (unsigned)c[1] ? both : si;
+}
+
+// Workgroup -> (molecule, split), XCD aware.  Workgroups are dealt to the 8 XCDs round-robin in linear-id order
+// (id = blockIdx.y * gridDim.x + blockIdx.x), and every XCD has its own L2.  The S workgroups of one molecule
+// gather the same x1 / d(agg) rows, so they are given ids that are equal mod 8: ids are taken in groups of
+// 8 S = 8 molecules x S splits, id = 8 S g + 8 split + r  <->  molecule 8 g + r.  The last n_mol % 8 molecules
+// keep the plain (molecule-major) order.
+__device__ __forceinline__ void wg_to_mol_split(int& m, int& split) {
+  const int S = gridDim.x, n_mol = gridDim.y;
+  const int lid = blockIdx.y * S + blockIdx.x;
+  const int grouped = (n_mol & ~7) * S;
+  if (lid < grouped) {
+    const int g = lid / (8 * S), rem = lid - g * 8 * S;
+    split = rem >> 3;
+    m = 8 * g + (rem & 7);
+  } else {
+    m = blockIdx.y;
+    split = blockIdx.x;
+  }
+}
+
+}  // namespace

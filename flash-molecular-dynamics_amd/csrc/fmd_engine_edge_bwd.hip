@@ -1,0 +1,457 @@
+// Fused engine, backward pair kernel: gradient of one interaction block's filter network and message passing with
+// respect to x1 (-> gx1 aggregate) and to the pair distance (-> dE/dd, including the d/dd of the cutoff that the
+// reference's Triton path drops).  Replaces K6/K7 + K10/K2 (kernels/cfconv_kernels.py:973-1035,
+// 1174-1208,178-258; csr_kernels.py:302-396) and the autograd chain through them on the whole-path route.
+#include "fmd_engine.h"
+
+namespace {
+// =================================================================================================
+// fp32-grade backward pair kernel, split-operand fp16 MFMA, wave specialised (see edge_fwd_split_kernel).
+//   producers (waves 4-7): rbf and d(rbf)/dd, L0 and z' = W0 . rbf' (12 + 12 MFMA), tanh, hidden tiles
+//                          -> LDS; later u = gW . W1 (24 MFMA) and the per-pair reduction to dE/dd
+//   consumers (waves 0-3): L1 recomputed (24 MFMA), gathers of x1 / d(agg) rows, the gW tile -> LDS,
+//                          gx1 aggregate update in LDS
+// One LDS region carries the hidden tiles (fp16 hi, lo) and then the gW tile (u32 = hi | lo << 16).
+// Barriers per tile: A hidden visible, B hidden consumed, C gW visible, D gW consumed + partial sums.
+// =================================================================================================
+struct SegRegsB {             // consumer state of one tile (register r = 4q + e <-> entry 8q+4h+e)
+  uint32_t oi[4], oj[16];
+  float xi[4], xj[16], gi[4], gj[16];
+};
+
+// FS: feature-split mode for molecules of 284..566 beads, see edge_fwd_split_kernel (each of the molecule's two
+// workgroups: all tiles, 64 features of gx1, its own dE/dd slab -- the u GEMM only sees its 64 features of gW).
+template <int NS0, bool NEED_GX1, bool FIRST, bool SHARE, bool HALF, bool FS>
+__global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
+  _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
+  // the gW tile reuses the two fp16 tiles (hi, lo), [pair][feature]
+  float* red = smem + TILE_FLOATS + 128;                         // [4][32]
+  float* cen_l = red + 128;                                      // [64] rbf centres
+  float* b0_l = cen_l + 64;                                      // [128] filter layer-0 bias
+  // SHARE: the Gaussians of a tile are computed once, by the consumers (consumer w: k-step w), and cross
+  // LDS as split fragments [half k-step][hi, lo][pair] x 16 B; the producers then run W0 and
+  // Wc = W0 diag(centre - c0) on the same fragments (W0 (raw (d - centre)) = (d - c0) W0 raw - Wc raw).
+  float* frag_l = b0_l + 128;                                    // [nb][2][32] x 16 B   (SHARE only)
+  float* gx1 = frag_l + (SHARE ? a.nb * 256 : 0);                // [n][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
+  const bool producer = wave >= 4;   // wave-uniform
+  const int w = wave & 3;            // feature slice
+  int m, split;
+  wg_to_mol_split(m, split);
+  const int64_t a0 = a.mol_ptr[m];
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
+  const int np = a.npairs[m];
+  constexpr int AW = FS ? 64 : F;  // gx1 row width kept in LDS
+  if (NEED_GX1)
+    for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 64) cen_l[tid] = a.centers[tid];
+  if (tid < 128) b0_l[tid] = a.b0[tid];
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const float* pdcut = a.pdc + (int64_t)m * a.cap;
+  float* pgd = a.pgd + (int64_t)m * a.cap + (FS ? split * a.pgd_stride : 0);  // FS: one dE/dd slab per half
+  const int ntiles = (np + 31) >> 5;
+  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
+  const int T0 = FS ? 0 : split;     // its first tile
+  const int last_base = (ntiles - 1) * 32;
+  __syncthreads();
+  if (T0 < ntiles) {  // uniform over the workgroup
+    if (producer) {
+      // ------------------------------------------------------------------ producer waves
+      f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) {
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        if (SHARE && !HALF) {
+          ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[(w * 4 + s) * 64 + lane];
+          acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
+        }
+      }
+      constexpr int NKU = FS ? 4 : 8;          // k-steps of the u GEMM: the features of gW this workgroup holds
+      const int ku0 = FS ? 4 * split : 0;
+#pragma unroll
+      for (int s = 0; s < NKU; ++s) {
+        wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + ku0 + s) * 64 + lane];
+        if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + ku0 + s) * 64 + lane];
+      }
+      // meta of the tile to stage next (lane = pair view)
+      float d_n, c_n, dc_n, gd_n = 0.f;
+      auto fetch = [&](int t) {
+        const int base = min(t * 32, last_base);
+        d_n = pdist[base + c32];
+        c_n = pcut[base + c32];
+        dc_n = pdcut[base + c32];
+        if (!FIRST) gd_n = pgd[base + c32];
+      };
+      // staged tile ("nx") and tile whose reduction is pending ("cu")
+      f16x4 hh[4], hl[4];
+      // k = d(message weight)/dd per unit u: C (1-h^2) z' + C' h   (one array: registers are tight)
+      float k_nx[16], gd_nx = 0.f;
+      float k_cu[16], gd_cu = 0.f;
+      const float gl = a.gamma * LOG2E;
+      auto compute = [&](int t_fetch) {
+        const float d = d_n, C = c_n, dC = dc_n;
+        gd_nx = gd_n;
+        fetch(t_fetch);
+        f32x16 z1 = zero16(), z2 = zero16(), p1 = zero16(), p2 = zero16();
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) {
+          f32x4 c0, c1;
+          if (!SHARE) {
+            c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
+            c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
+          }
+          // z  = C G0 + b0,            G0 = W0 raw
+          // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
+          f16x8 bh, bl, ph, pl;
+          if (SHARE) {  // p accumulates Gc = Wc raw
+            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
+            bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
+            if (HALF) {  // W16A16: the second record holds f16(raw (d - centre)); no cancellation-prone Wc form
+              z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
+            } else {
+              mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
+              mfma_split(ach[s], acl[s], bh, bl, p1, p2);
+            }
+          } else {
+            rbf_fragments<true, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
+            mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, z1, z2);
+            mfma_prod<HALF>(a0h[s], a0l[s], ph, pl, p1, p2);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
+        }
+        const float g2c = 2.0f * a.gamma * C, dm = d - a.c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_l + 32 * w + 8 * q + 4 * h);
+          uint32_t th[2], tl[2];
+#pragma unroll
+          for (int ep = 0; ep < 2; ++ep) {
+            const int r = 4 * q + 2 * ep;
+            const f32x2 g0 = comb2<HALF>(z1, z2, r);
+            f32x2 g1 = comb2<HALF>(p1, p2, r);
+            if (SHARE && !HALF) g1 = splat2(dm) * g0 - g1;
+            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
+            // the tile carries C h: L1 then yields W = filt C
+            if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
+            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
+            const f32x2 kk = splat2(C) * ((splat2(1.0f) - hv * hv) * (splat2(g2c) * g1 + splat2(dC) * g0)) +
+                             splat2(dC) * hv;
+            k_nx[r] = kk[0];
+            k_nx[r + 1] = kk[1];
+          }
+          __builtin_memcpy(&hh[q], th, 8);
+          __builtin_memcpy(&hl[q], tl, 8);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
+        // ... and the k array too: left alone, the compiler sinks its arithmetic behind the reduction
+        // and carries both accumulators of G1 and the hidden values (48 registers) across it instead
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(k_nx[r]));
+      };
+      auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+          if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+        }
+      };
+      auto rotate = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) k_cu[r] = k_nx[r];
+        gd_cu = gd_nx;
+      };
+      fetch(T0);
+      if (SHARE) __syncthreads();  // fragments of the first tile visible
+      compute(T0 + S);
+      if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
+      rotate();
+      put();
+      __syncthreads();  // A(first)
+      for (int t = T0; t < ntiles; t += S) {
+        compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+        __syncthreads();     // B(t)
+        __syncthreads();     // C(t): gW(t) visible
+        // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
+        f32x16 u1 = zero16(), u2 = zero16();
+        {
+          // gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
+          const _Float16* gph = hid_hi + c32 * LDH + 8 * h + 16 * ku0;
+          const _Float16* gpl = hid_lo + c32 * LDH + 8 * h + 16 * ku0;
+          f16x8 bh = *reinterpret_cast<const f16x8*>(gph), bl = *reinterpret_cast<const f16x8*>(gpl);
+          static_for<0, NKU>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 nh = bh, nl = bl;
+            if constexpr (s + 1 < NKU) {
+              nh = *reinterpret_cast<const f16x8*>(gph + 16 * (s + 1));
+              nl = *reinterpret_cast<const f16x8*>(gpl + 16 * (s + 1));
+            }
+            mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
+            bh = nh; bl = nl;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 pr = comb2<HALF>(u1, u2, r) *
+                           f32x2{k_cu[r], k_cu[r + 1]};
+          tot += pr[0] + pr[1];
+        }
+        tot = fmd_xor32_sum(tot);
+        if (h == 0) red[w * 32 + c32] = tot;
+        __syncthreads();     // D(t): gW consumed, partial sums visible
+        if (w == 0 && h == 0) {
+          const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
+          pgd[t * 32 + c32] = FIRST ? sum : gd_cu + sum;
+        }
+        put();               // hidden tiles of t+S
+        rotate();
+        __syncthreads();     // A(t+S)
+      }
+    } else {
+      // ------------------------------------------------------------------ consumer waves
+      const bool slice_owner = !FS || w < 2;  // FS: waves 2, 3 only share Gaussians and keep the barriers
+      const int cw = FS ? 2 * split + (w & 1) : w;
+      f16x8 b1h[8], b1l[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
+      }
+      const int col = 32 * cw + c32;
+      const uint32_t col4 = (uint32_t)col * 4u;
+      const int lds_adj = (32 * (w & 1) + c32) * 4 - (int)(col4 >> 1);
+      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F);
+      char* gx1b = reinterpret_cast<char*>(gx1);
+      SegRegsB X;
+      uint32_t oj_m[16], oi_m[4];
+      float d_m = 0.f;  // SHARE: distance of pair c32 of the fetched tile
+      auto fetch_meta = [&](int t) {
+        const int base = min(t * 32, last_base);
+        if (SHARE) d_m = pdist[base + c32];
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+          oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
+          oi_m[q] = poi[base + 8 * q + 4 * h];
+        });
+      };
+      auto fill = [&]() {  // X <- fetched tile: offsets, gathers of x1 and d/d(agg) rows
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+          }
+        });
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+          X.gi[q] = *reinterpret_cast<const float*>(gab + X.oi[q]);
+        });
+        static_for<0, 16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          X.xj[r] = *reinterpret_cast<const float*>(x1b + X.oj[r]);
+          X.gj[r] = *reinterpret_cast<const float*>(gab + X.oj[r]);
+        });
+      };
+      // SHARE: Gaussians of one tile, k-step w of this wave, as split fragments in LDS
+      const float gl = a.gamma * LOG2E;
+      auto share_fragments = [&]() {  // of the tile whose meta were fetched last
+        if (w < NS0 && 2 * w + h < a.nb) {
+          const float d = d_m;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h);
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h + 4);
+          f16x8 bh, bl, ph, pl;
+          rbf_fragments<HALF, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
+          const int blk = 2 * w + h;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
+        }
+      };
+      fetch_meta(T0);
+      fill();
+      if (SHARE) share_fragments();
+      fetch_meta(T0 + S);
+      if (SHARE) {
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+      }
+      __syncthreads();  // A(first)
+      for (int t = T0; t < ntiles; t += S) {
+        if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
+          fetch_meta(t + 2 * S);
+          __syncthreads();  // B(t)
+          __syncthreads();  // C(t)
+          if (SHARE) share_fragments();
+          __syncthreads();  // D(t)
+          __syncthreads();  // A(t+S)
+          continue;
+        }
+        // L1 recomputed: filt slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16(), acc2 = zero16();
+        {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        f32x16 fl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fl[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
+        // gW = x1[i] g[j] + x1[j] g[i], split two values at a time: gwh[p] = hi halves of entries 2p, 2p+1,
+        // gwl[p] = their lo halves
+        f16x2 gwh[8], gwl[8];
+#pragma unroll
+        for (int p2 = 0; p2 < 8; ++p2) {
+          const int r = 2 * p2;
+          const f32x2 gw = f32x2{X.xi[r >> 2], X.xi[r >> 2]} * f32x2{X.gj[r], X.gj[r + 1]} +
+                           f32x2{X.xj[r], X.xj[r + 1]} * f32x2{X.gi[r >> 2], X.gi[r >> 2]};
+          uint32_t hw, lw = 0;
+          if (HALF) hw = half_pair(gw);
+          else split_pair(gw, hw, lw);
+          __builtin_memcpy(&gwh[p2], &hw, 4);
+          __builtin_memcpy(&gwl[p2], &lw, 4);
+        }
+        asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
+        // The aggregate update and the refill of X need nothing from the producers: they run here,
+        // while the producers are still staging the next tile, not between the later barriers.
+        if (NEED_GX1) {   // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j)
+          static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float Wq[4], vj[4];
+            float si = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              Wq[e] = fl[4 * q + e];  // already filt * C
+              vj[e] = *reinterpret_cast<const float*>(gx1b + lo(X.oj[4 * q + e]));
+              si += X.gj[4 * q + e] * Wq[e];
+            }
+            const float cval = *reinterpret_cast<const float*>(gx1b + lo(X.oi[q]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wq[e];
+            si = fmd_segment_sum(si, X.oi[q]);
+            *reinterpret_cast<float*>(gx1b + lo(X.oi[q])) = cval + si;
+          });
+        }
+        fill();           // X <- tile t+S
+        fetch_meta(t + 2 * S);
+        __syncthreads();  // B(t): hidden tiles consumed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // ds_write_b16 of each half
+          hid_hi[tile_row(r, h) * LDH + col] = gwh[r >> 1][r & 1];
+          if (!HALF) hid_lo[tile_row(r, h) * LDH + col] = gwl[r >> 1][r & 1];
+        }
+        __syncthreads();  // C(t): gW visible
+        // the producers read fragments only while staging (between A and B): the tile they stage in the
+        // next iteration, t + 2S, is written here, in the consumers' idle window
+        if (SHARE) share_fragments();
+        __syncthreads();  // D(t)
+        __syncthreads();  // A(t+S)
+      }
+    }
+  }
+  if (NEED_GX1) {
+    __syncthreads();
+    float* out = a.slabs + split * a.slab_stride + a0 * F;
+    if (FS) {  // this half's 64 features, zeros in the other half
+      for (int i = tid * 4; i < n * 64; i += 2048) {
+        const int row = i >> 6, c = i & 63;
+        *reinterpret_cast<f32x4*>(out + row * F + 64 * split + c) = *reinterpret_cast<const f32x4*>(gx1 + i);
+        *reinterpret_cast<f32x4*>(out + row * F + 64 * (1 - split) + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      for (int i = tid * 4; i < n * F; i += 2048)
+        *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(gx1 + i);
+    }
+  }
+}
+
+}  // namespace
+
+namespace fmd_eng {
+
+#define FMD_BWD_ALL(M_)                                                                         \
+  M_(true, true, false, false, false) M_(true, false, false, false, false)                     \
+  M_(false, true, false, false, false) M_(false, false, false, false, false)                   \
+  M_(true, true, false, true, false) M_(true, false, false, true, false)                       \
+  M_(false, true, false, true, false) M_(false, false, false, true, false)                     \
+  M_(true, true, true, false, false) M_(true, false, true, false, false)                       \
+  M_(false, true, true, false, false) M_(false, false, true, false, false)                     \
+  M_(true, true, true, true, false) M_(true, false, true, true, false)                         \
+  M_(false, true, true, true, false) M_(false, false, true, true, false)                       \
+  M_(true, true, true, false, true) M_(true, false, true, false, true)                         \
+  M_(false, true, true, false, true) M_(false, false, true, false, true)                       \
+  M_(true, true, true, true, true) M_(true, false, true, true, true)                           \
+  M_(false, true, true, true, true) M_(false, false, true, true, true)
+
+template <int NS0>
+static int set_attrs() {
+#define FMD_ONE(N_, F_, S_, H_, FS_)                                                                          \
+  if (hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_>,                       \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)      \
+    return FMD_ELAUNCH;
+  FMD_BWD_ALL(FMD_ONE)
+#undef FMD_ONE
+  return FMD_OK;
+}
+int setup_edge_bwd_attrs() {
+  const int rc = set_attrs<2>();
+  return rc != FMD_OK ? rc : set_attrs<4>();
+}
+
+template <int NS0>
+static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 grid, hipStream_t s) {
+  // [tile region][red 128][centres 64][bias 128]([fragments])[gx1 rows]; block 0 (no gx1) keeps no aggregate
+  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
+  const size_t frag = (size_t)a.nb * 1024;
+  // shared-Gaussian form when its fragment region fits next to the aggregate (block 0 keeps none)
+  const size_t lds_sh = need ? lds + frag : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag;
+  const bool share = lds_sh <= MAX_LDS_BYTES;
+  if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
+#define FMD_ONE(N_, F_, S_, H_, FS_)                                                       \
+  if (need == N_ && first == F_ && (share || a.fs) == S_ && half == H_ && a.fs == FS_) {   \
+    edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a); \
+    return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                         \
+  }
+  FMD_BWD_ALL(FMD_ONE)
+#undef FMD_ONE
+  return FMD_EUNSUPPORTED;
+}
+
+int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol,
+                    hipStream_t s) {
+  const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
+  return num_rbf <= 32 ? launch_bwd<2>(a, half, need_gx1, first, grid, s)
+                       : launch_bwd<4>(a, half, need_gx1, first, grid, s);
+}
+
+}  // namespace fmd_eng

@@ -1,0 +1,333 @@
+// Fused engine, forward pair kernel: filter network (models/mlp.py:41-57 as built at schnet.py:813-817) and the
+// CFConv message passing (schnet.py:706-715) of one interaction block over the undirected pair list; the molecule's
+// aggregate stays in LDS.  Replaces K3/K4/K5 + K9 of the reference (kernels/cfconv_kernels.py:469-540,657-720,
+// 780-832; csr_kernels.py:625-724) on the whole-path route.
+#include "fmd_engine.h"
+
+namespace {
+// Wave-specialised pair kernels: 8 waves per workgroup, two per SIMD (waves w and w + 4 share one).
+//   waves 0-3 (consumers): own the 32-feature slices -- L1 MFMAs, x1 gathers, aggregate update in LDS
+//   waves 4-7 (producers): rbf values on the VALU, L0 MFMAs, tanh, hidden tile -> LDS
+// Per tile two workgroup barriers:  A(t) "hidden(t) visible", B(t) "hidden(t) consumed".
+struct SegRegs {              // consumer state of one 32-entry tile, register r = 4q + e <-> entry 8q+4h+e
+  uint32_t oi[4];             // centre row byte offset of segment q (+ this lane's column)
+  uint32_t oj[16];            // neighbour row byte offsets
+  float cr[16];               // C(d) per entry
+  float xi[4], xj[16];        // gathered x1[centre], x1[neighbour] (this lane's feature)
+};
+
+// =================================================================================================
+// fp32-grade forward pair kernel on the fp16 MFMA (v_mfma_f32_32x32x16_f16) with split operands:
+// every operand x is carried as hi = f16(x), lo = f16((x - hi) * 2048) and a product a.b is
+// a_hi.b_hi + (a_hi.b_lo + a_lo.b_hi) / 2048, accumulated in fp32 (two accumulators).  The dropped
+// a_lo.b_lo term is 2^-22 relative: measured error of a 128-deep contraction 2e-7, the same as the
+// fp32 MFMA, at 3/16 of its MFMA cycles.  Same wave specialisation and segment scheme as
+// edge_fwd_ws_kernel; the hidden tile crosses LDS as two fp16 tiles (hi, lo).
+// =================================================================================================
+// FS ("feature split", molecules of 284..566 beads): the aggregate of the whole molecule does not fit the LDS at 128
+// features per row, so each of the molecule's TWO workgroups keeps 64 features of it (blockIdx.x = which half),
+// walks ALL tiles, stages the full hidden tile (the producers' work is done twice per molecule) and runs two
+// consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
+// SH: the tile's Gaussians are computed once, by the consumers (consumer w: k-step w) between barriers B and A,
+// and reach the producers as split fragments in LDS (see the backward kernel); used when the region fits.
+template <int NS0, bool HALF, bool FS, bool SH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
+__global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
+  _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
+  float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
+  float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
+  const bool producer = wave >= 4;   // wave-uniform
+  const int w = wave & 3;            // feature slice
+  int m, split;
+  wg_to_mol_split(m, split);
+  const int64_t a0 = a.mol_ptr[m];
+  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
+  const int np = a.npairs[m];
+  constexpr int AW = FS ? 64 : F;  // aggregate row width kept in LDS
+  for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t* poi = a.poi + (int64_t)m * a.cap;
+  const uint32_t* poj = a.poj + (int64_t)m * a.cap;
+  const float* pdist = a.pd + (int64_t)m * a.cap;
+  const float* pcut = a.pc + (int64_t)m * a.cap;
+  const int ntiles = (np + 31) >> 5;
+  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
+  const int T0 = FS ? 0 : split;     // its first tile
+  const int last_base = (ntiles - 1) * 32;
+  __syncthreads();
+  if (T0 < ntiles) {  // uniform over the workgroup
+    if (producer) {
+      // ------------------------------------------------------------------ producer waves
+      f16x8 a0h[NS0], a0l[NS0];
+      f32x4 cen[SH ? 1 : 2 * NS0], b0r[4];
+      const float gl = a.gamma * LOG2E;
+#pragma unroll
+      for (int s = 0; s < NS0; ++s) {
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        if (!SH) {
+          cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
+          cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h);
+      float d_n = pdist[min(T0 * 32, last_base) + c32], c_n = pcut[min(T0 * 32, last_base) + c32];
+      f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
+      auto compute = [&](int t_next) {
+        const float d = d_n, C = c_n;
+        const int nb = min(t_next * 32, last_base);
+        d_n = pdist[nb + c32];
+        c_n = pcut[nb + c32];
+        f32x16 acc1 = zero16(), acc2 = zero16();
+#pragma unroll
+        for (int s = 0; s < NS0; ++s) {
+          f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
+          if (SH) {
+            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
+            if (!HALF) bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
+          } else {
+            rbf_fragments<false, HALF>(d, gl, cen[SH ? 0 : 2 * s], cen[SH ? 0 : 2 * s + 1], bh, bl, ph, pl);
+          }
+          mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, acc1, acc2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t th[2], tl[2];
+#pragma unroll
+          for (int ep = 0; ep < 2; ++ep) {
+            const int r = 4 * q + 2 * ep;
+            // z = C (W0 raw) + b0 ; the tile carries C tanh(z): the consumers' L1 then yields W = filt C
+            const f32x2 g0 = comb2<HALF>(acc1, acc2, r);
+            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b0r[q][2 * ep], b0r[q][2 * ep + 1]});
+            if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
+            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
+          }
+          __builtin_memcpy(&hh[q], th, 8);
+          __builtin_memcpy(&hl[q], tl, 8);
+        }
+        // pin the computation in front of the barrier that follows
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
+      };
+      auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+          if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+        }
+      };
+      if (SH) __syncthreads();  // fragments of the first tile visible
+      compute(T0 + S);
+      if (SH) __syncthreads();  // ... and consumed: the consumers write the second tile's
+      put();
+      __syncthreads();  // A(first)
+      for (int t = T0; t < ntiles; t += S) {
+        compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        __syncthreads();     // B(t)
+        put();
+        __syncthreads();     // A(t+S)
+      }
+    } else {
+      // ------------------------------------------------------------------ consumer waves
+      if (FS && w >= 2) {  // no feature slice for this wave in FS mode: keep the barrier protocol
+        __syncthreads();  // A(first)
+        for (int t = T0; t < ntiles; t += S) {
+          __syncthreads();  // B(t)
+          __syncthreads();  // A(t+S)
+        }
+      } else {
+      const int cw = FS ? 2 * split + w : w;  // feature slice of this wave
+      f16x8 b1h[8], b1l[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
+        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
+      }
+      const uint32_t col4 = (uint32_t)(32 * cw + c32) * 4u;
+      // byte offset inside the LDS aggregate of the row/column a global offset o = row * 512 + col4 names
+      const int lds_adj = (32 * w + c32) * 4 - (int)(col4 >> 1);
+      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      char* aggb = reinterpret_cast<char*>(agg);
+      SegRegs X;
+      uint32_t oj_m[16], oi_m[4];
+      auto fetch_meta = [&](int t) {
+        const int base = min(t * 32, last_base);
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
+          oj_m[4 * q] = v[0]; oj_m[4 * q + 1] = v[1]; oj_m[4 * q + 2] = v[2]; oj_m[4 * q + 3] = v[3];
+          oi_m[q] = poi[base + 8 * q + 4 * h];
+        });
+      };
+      auto fill = [&]() {  // X <- fetched tile: offsets and x1 gathers
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+          }
+        });
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+        });
+        static_for<0, 16>([&](auto rc) {
+          constexpr int r = decltype(rc)::value;
+          X.xj[r] = *reinterpret_cast<const float*>(x1b + X.oj[r]);
+        });
+      };
+      // aggregate update: segment q has one centre and distinct neighbours -> plain read-modify-write
+      auto message = [&](const f32x16& fl) {
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          float Wq[4], vj[4];
+          float si = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            Wq[e] = fl[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
+            vj[e] = *reinterpret_cast<const float*>(aggb + lo(X.oj[4 * q + e]));
+            si += X.xj[4 * q + e] * Wq[e];
+          }
+          const float cval = *reinterpret_cast<const float*>(aggb + lo(X.oi[q]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wq[e];
+          si = fmd_segment_sum(si, X.oi[q]);
+          // both halves store the same value to the same address
+          *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
+        });
+      };
+      // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
+      // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
+      // between the two barriers where the producers only write LDS.
+      // SH: Gaussians of one tile (k-step w of this wave) as split fragments in LDS
+      float d_m = 0.f;
+      f32x4 cs0, cs1;
+      if (SH && w < NS0) {
+        cs0 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h);
+        cs1 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h + 4);
+      }
+      auto fetch_d = [&](int t) {
+        if (SH) d_m = pdist[min(t * 32, last_base) + c32];
+      };
+      auto share_fragments = [&]() {  // of the tile whose distances were fetched last
+        if (SH && w < NS0 && 2 * w + h < a.nb) {
+          f16x8 bh, bl, ph, pl;
+          rbf_fragments<false, HALF>(d_m, a.gamma * LOG2E, cs0, cs1, bh, bl, ph, pl);
+          const int blk = 2 * w + h;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
+          if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
+        }
+      };
+      if (SH) {
+        fetch_d(T0);
+        share_fragments();
+        fetch_d(T0 + S);
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+        fetch_d(T0 + 2 * S);
+      }
+      fetch_meta(T0);
+      fill();            // X <- first tile (valid rows for the first, zero-weight, update)
+      f32x16 fl_prev = zero16();
+      __syncthreads();  // A(first)
+      for (int t = T0; t < ntiles; t += S) {
+        // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16(), acc2 = zero16();
+        {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        message(fl_prev);  // tile t-S (X holds its gathers)
+        fill();            // X <- tile t (meta fetched one tile ago; lands before the next update)
+        fetch_meta(t + S);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fl_prev[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
+        asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
+        __syncthreads();  // B(t): hidden tiles consumed
+        if (SH) {  // the producers only write the hidden tile now: the fragments they stage from next are replaced
+          share_fragments();
+          fetch_d(t + 3 * S);
+        }
+        __syncthreads();  // A(t+S)
+      }
+      message(fl_prev);  // last tile
+      }
+    }
+  }
+  __syncthreads();
+  float* out = a.slabs + split * a.slab_stride + a0 * F;
+  if (FS) {  // this half's 64 features, zeros in the other half (the node kernels add the slabs)
+    for (int i = tid * 4; i < n * 64; i += 2048) {
+      const int row = i >> 6, c = i & 63;
+      *reinterpret_cast<f32x4*>(out + row * F + 64 * split + c) = *reinterpret_cast<const f32x4*>(agg + i);
+      *reinterpret_cast<f32x4*>(out + row * F + 64 * (1 - split) + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+    for (int i = tid * 4; i < n * F; i += 2048)
+      *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
+  }
+}
+
+}  // namespace
+
+namespace fmd_eng {
+
+int setup_edge_fwd_attrs() {
+  const void* fns[] = {(const void*)edge_fwd_split_kernel<2, false, false, false>, (const void*)edge_fwd_split_kernel<2, true, false, false>,
+                       (const void*)edge_fwd_split_kernel<2, false, true, false>,  (const void*)edge_fwd_split_kernel<2, true, true, false>,
+                       (const void*)edge_fwd_split_kernel<2, false, false, true>,
+                       (const void*)edge_fwd_split_kernel<4, false, false, false>, (const void*)edge_fwd_split_kernel<4, true, false, false>,
+                       (const void*)edge_fwd_split_kernel<4, false, true, false>,  (const void*)edge_fwd_split_kernel<4, true, true, false>,
+                       (const void*)edge_fwd_split_kernel<4, false, false, true>};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)
+      return FMD_ELAUNCH;
+  return FMD_OK;
+}
+
+template <int NS0>
+static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
+  // [tile region][red 128][centres 64][bias 128][aggregate rows] (the backward kernel's carve: one size for both)
+  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
+  // shared-Gaussian form when its fragment region fits next to the aggregate
+  // (not in W16A16: without operand splits the Gaussians are cheap for the producers, and the consumers' extra work
+  //  between B and A costs more than it saves: 0.156 vs 0.144 ms)
+  const size_t lds_sh = (size_t)(TILE_FLOATS + 128 + a.nb * 256 + a.max_beads * F) * sizeof(float);
+  const bool sh = !a.fs && !half && lds_sh <= MAX_LDS_BYTES;
+  if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
+  if (a.fs && half) edge_fwd_split_kernel<NS0, true, true, false><<<grid, 512, lds, s>>>(a);
+  else if (a.fs) edge_fwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(a);
+  else if (sh) edge_fwd_split_kernel<NS0, false, false, true><<<grid, 512, lds_sh, s>>>(a);
+  else if (half) edge_fwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(a);
+  else edge_fwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(a);
+  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+}
+
+int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
+  const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
+  return num_rbf <= 32 ? launch_fwd<2>(a, half, grid, s) : launch_fwd<4>(a, half, grid, s);
+}
+
+}  // namespace fmd_eng

@@ -1,0 +1,422 @@
+// Fused engine, host side: weight packing, workspace carve-up, the launch sequence of one force evaluation and the
+// C-ABI entry points fmd_schnet_* (include/flashmd_hip.h).  Replaces SchNet.forward + GradientsOut.forward of the
+// reference (models/schnet.py:178-369, models/gradients.py:226-290) for StandardSchNet models with
+// hidden = filters = 128.  The kernels live in fmd_engine_{pairs,edge_fwd,edge_bwd,node}.hip.
+#include <atomic>
+#include <vector>
+
+#include "fmd_engine.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// packed weight layout (floats)
+// ---------------------------------------------------------------------------------------------
+struct BlockOff {
+  int64_t b0, l1, l1t, l2, b2, l2t, l3, b3, l3t;
+  int64_t q0h, q0l, q1h, q1l, q1th, q1tl;  // fp16 hi/lo split operands of the filter network
+  int64_t q0ch, q0cl;                      // W0 with column k scaled by (centre_k - cutoff/2): backward only
+};
+struct PackLayout {
+  int64_t emb, centers, blocks, block_stride, outs, out_stride, emb_x1, total;
+};
+constexpr int64_t BLOCK_FLOATS = 3 * F + 6 * (int64_t)SLICE + 4 * Q0_FLOATS + 4 * Q1_FLOATS;
+constexpr int64_t OUT_FLOATS = 2 * (int64_t)SLICE + F;
+
+PackLayout pack_layout(const fmd_schnet_desc* d) {
+  PackLayout L;
+  L.emb = 0;
+  L.centers = (int64_t)d->embedding_size * F;
+  L.blocks = L.centers + 64;
+  L.block_stride = BLOCK_FLOATS;
+  L.outs = L.blocks + (int64_t)d->num_blocks * BLOCK_FLOATS;
+  L.out_stride = OUT_FLOATS;
+  L.emb_x1 = L.outs + (int64_t)d->num_out * OUT_FLOATS;  // [embedding_size][128]: embedding lin1(block 0)^T
+  L.total = L.emb_x1 + (int64_t)d->embedding_size * F;
+  return L;
+}
+BlockOff block_off(const PackLayout& L, int l) {
+  BlockOff o;
+  int64_t p = L.blocks + l * L.block_stride;
+  o.b0 = p; p += F;
+  o.l1 = p; p += SLICE;
+  o.l1t = p; p += SLICE;
+  o.l2 = p; p += SLICE;
+  o.b2 = p; p += F;
+  o.l2t = p; p += SLICE;
+  o.l3 = p; p += SLICE;
+  o.b3 = p; p += F;
+  o.l3t = p; p += SLICE;
+  o.q0h = p; p += Q0_FLOATS;
+  o.q0l = p; p += Q0_FLOATS;
+  o.q1h = p; p += Q1_FLOATS;
+  o.q1l = p; p += Q1_FLOATS;
+  o.q1th = p; p += Q1_FLOATS;
+  o.q1tl = p; p += Q1_FLOATS;
+  o.q0ch = p; p += Q0_FLOATS;
+  o.q0cl = p; p += Q0_FLOATS;
+  return o;
+}
+
+// fp16 hi/lo split of an operand for v_mfma_f32_32x32x16_f16: x ~ hi + lo / 2048 with hi = f16(x),
+// lo = f16((x - hi) * 2048).  M is [n_out][n_k] row-major (or its transpose when `transposed`): the operand that
+// multiplies a row tile as out[row][o] = sum_k a[row][k] * M[o][k].  Record (w, s, lane) holds the 8 halves
+// M[32w + (lane&31)][16s + 8(lane>>5) + j], zero outside the matrix (the A-operand and the B-operand fragment of that
+// instruction index their matrix the same way).
+void pack_split(float* dst_hi, float* dst_lo, const float* M, int n_out, int n_k, int n_steps,
+                bool transposed) {
+  _Float16* hi = reinterpret_cast<_Float16*>(dst_hi);
+  _Float16* lo = reinterpret_cast<_Float16*>(dst_lo);
+  for (int w = 0; w < 4; ++w)
+    for (int s = 0; s < n_steps; ++s)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int o = 32 * w + (l & 31), k = 16 * s + 8 * (l >> 5) + j;
+          float v = 0.f;
+          if (o < n_out && k < n_k) v = transposed ? M[(int64_t)k * n_out + o] : M[(int64_t)o * n_k + k];
+          const _Float16 h = (_Float16)v;
+          const int64_t idx = (((int64_t)w * n_steps + s) * 64 + l) * 8 + j;
+          hi[idx] = h;
+          lo[idx] = (_Float16)((v - (float)h) * 2048.0f);
+        }
+}
+// node-kernel operand: hi record followed by lo record (SLICE floats)
+void pack_node(float* dst, const float* M, int n_out, int n_k, bool transposed) {
+  pack_split(dst, dst + Q1_FLOATS, M, n_out, n_k, 8, transposed);
+}
+
+int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Workspace {
+  float *x, *gx, *gagg, *e_node, *pd, *pc, *pdc, *pgd;
+  float* x1[8];
+  float* t[8];
+  float* slabs;
+  uint32_t *poi, *poj;
+  int32_t* npairs;
+  int32_t* report;  // [n_mol][3] pairs_kernel -> finish_kernel
+  int64_t total;
+};
+
+constexpr int MAX_SPLIT = 32;  // workgroups per molecule (small batches: 8 molecules x 32 = 256 workgroups)
+int device_cus() {
+  int cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  return cus;
+}
+int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
+  if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
+  const int cus = device_cus();
+  int64_t s = n_mol > 0 ? (cus + n_mol - 1) / n_mol : 1;
+  if (s < 1) s = 1;
+  if (s > MAX_SPLIT) s = MAX_SPLIT;
+  return (int)s;
+}
+
+Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t n_nodes, int64_t cap,
+                   int n_split) {
+  Workspace w;
+  char* p = reinterpret_cast<char*>(base);
+  auto take = [&](int64_t bytes) {
+    char* q = p;
+    p += align256(bytes);
+    return q;
+  };
+  const int64_t nf = n_nodes * F * (int64_t)sizeof(float);
+  w.x = (float*)take(nf);
+  w.gx = (float*)take(nf);
+  w.gagg = (float*)take(nf);
+  for (int l = 0; l < d->num_blocks; ++l) {
+    w.x1[l] = (float*)take(nf);
+    w.t[l] = (float*)take(nf);
+  }
+  w.slabs = (float*)take(nf * n_split);
+  w.e_node = (float*)take(n_nodes * 4);
+  w.poi = (uint32_t*)take(n_mol * cap * 4);
+  w.poj = (uint32_t*)take(n_mol * cap * 4);
+  w.pd = (float*)take(n_mol * cap * 4);
+  w.pc = (float*)take(n_mol * cap * 4);
+  w.pdc = (float*)take(n_mol * cap * 4);
+  w.pgd = (float*)take(2 * n_mol * cap * 4);  // second slab: feature-split mode
+  w.npairs = (int32_t*)take(n_mol * 4);
+  w.report = (int32_t*)take(n_mol * 12);
+  w.total = p - reinterpret_cast<char*>(base);
+  return w;
+}
+
+bool desc_ok(const fmd_schnet_desc* d) {
+  if (!d) return false;
+  if (d->hidden != F || d->num_rbf < 2 || d->num_rbf > 64) return false;
+  if (d->num_blocks < 1 || d->num_blocks > 8) return false;
+  if (d->num_out < 2 || d->num_out > 3) return false;
+  for (int k = 0; k < d->num_out; ++k)
+    if (d->out_width[k] < 1 || d->out_width[k] > F) return false;
+  if (d->out_width[d->num_out - 1] != 1) return false;
+  if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_W16A16) return false;
+  if (d->embedding_size < 1) return false;
+  return true;
+}
+
+
+// one-time, per-device raise of the kernels' dynamic-LDS ceilings (idempotent; nothing a caller can observe)
+int ensure_kernel_attrs() {
+  static std::atomic<int> done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FMD_ELAUNCH;
+  if (done[dev].load(std::memory_order_acquire)) return FMD_OK;
+  int rc = setup_pairs_attrs();
+  if (rc == FMD_OK) rc = setup_edge_fwd_attrs();
+  if (rc == FMD_OK) rc = setup_edge_bwd_attrs();
+  if (rc == FMD_OK) done[dev].store(1, std::memory_order_release);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int64_t fmd_schnet_pack_bytes(const fmd_schnet_desc* desc) {
+  if (!desc_ok(desc)) return FMD_EINVAL;
+  return pack_layout(desc).total * (int64_t)sizeof(float);
+}
+
+extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_weights* wt,
+                               const float* centers, void* packed_host) {
+  if (!desc_ok(desc) || !wt || !centers || !packed_host || !wt->embedding || !wt->blocks) return FMD_EINVAL;
+  const PackLayout L = pack_layout(desc);
+  float* out = reinterpret_cast<float*>(packed_host);
+  // node operands in split (hi/lo fp16) form; W16A16 keeps lin1/lin2/lin fp32-grade like the reference
+  memset(out, 0, L.total * sizeof(float));
+  memcpy(out + L.emb, wt->embedding, (size_t)desc->embedding_size * F * sizeof(float));
+  for (int k = 0; k < desc->num_rbf; ++k) out[L.centers + k] = centers[k];
+  // The first block's x1 = lin1(embedding[type]) only depends on the bead type: one table row per type (fp64
+  // accumulation, rounded once), so the first node launch of a timestep is a gather instead of a GEMM.
+  if (desc->num_blocks > 0 && wt->blocks[0].lin1_w) {
+    const float* l1 = reinterpret_cast<const float*>(wt->blocks[0].lin1_w);
+    const float* em = reinterpret_cast<const float*>(wt->embedding);
+    for (int t = 0; t < desc->embedding_size; ++t)
+      for (int o = 0; o < F; ++o) {
+        double acc = 0.0;
+        for (int k = 0; k < F; ++k) acc += (double)em[(int64_t)t * F + k] * (double)l1[(int64_t)o * F + k];
+        out[L.emb_x1 + (int64_t)t * F + o] = (float)acc;
+      }
+  }
+  for (int l = 0; l < desc->num_blocks; ++l) {
+    const fmd_schnet_block_weights& b = wt->blocks[l];
+    if (!b.lin1_w || !b.f0_w || !b.f0_b || !b.f1_w || !b.lin2_w || !b.lin2_b || !b.lin_w || !b.lin_b)
+      return FMD_EINVAL;
+    const BlockOff o = block_off(L, l);
+    memcpy(out + o.b0, b.f0_b, F * sizeof(float));
+    if (desc->precision == FMD_PREC_W16A16)  // the fp16 filter network carries its bias in fp16 (gptq.py:178-184)
+      for (int f = 0; f < F; ++f) out[o.b0 + f] = (float)(_Float16)out[o.b0 + f];
+    pack_node(out + o.l1, b.lin1_w, F, F, false);
+    pack_node(out + o.l1t, b.lin1_w, F, F, true);
+    pack_node(out + o.l2, b.lin2_w, F, F, false);
+    memcpy(out + o.b2, b.lin2_b, F * sizeof(float));
+    pack_node(out + o.l2t, b.lin2_w, F, F, true);
+    pack_node(out + o.l3, b.lin_w, F, F, false);
+    memcpy(out + o.b3, b.lin_b, F * sizeof(float));
+    pack_node(out + o.l3t, b.lin_w, F, F, true);
+    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false);
+    {  // Wc[f][k] = (centre_k - cutoff/2) W0[f][k]:  W0 (raw (d - centre)) = (d - cutoff/2) W0 raw - Wc raw
+      std::vector<float> wc((size_t)F * desc->num_rbf);
+      const float c0 = 0.5f * desc->cutoff;
+      for (int f = 0; f < F; ++f)
+        for (int k = 0; k < desc->num_rbf; ++k)
+          wc[(size_t)f * desc->num_rbf + k] = (centers[k] - c0) * b.f0_w[(size_t)f * desc->num_rbf + k];
+      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, 4, false);
+    }
+    pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false);
+    pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
+  }
+  int in_w = F;
+  for (int k = 0; k < desc->num_out; ++k) {
+    if (!wt->out_w[k]) return FMD_EINVAL;
+    float* base = out + L.outs + k * L.out_stride;
+    const int ow = desc->out_width[k];
+    pack_node(base, wt->out_w[k], ow, in_w, false);
+    if (wt->out_b[k]) memcpy(base + SLICE, wt->out_b[k], ow * sizeof(float));
+    if (desc->precision == FMD_PREC_W16A16)
+      for (int f = 0; f < F; ++f) base[SLICE + f] = (float)(_Float16)base[SLICE + f];
+    pack_node(base + SLICE + F, wt->out_w[k], in_w, ow, true);  // (W^T)[o=in][k=out] = W[out][in]
+    in_w = ow;
+  }
+  return FMD_OK;
+}
+
+extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol,
+                                              int64_t n_nodes, int64_t max_pairs_per_mol) {
+  if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0 || max_pairs_per_mol < 0) return FMD_EINVAL;
+  const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
+  const int split = resolve_split(desc, n_mol);  // the slabs scale with it; >= 2 for the feature-split mode
+  return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
+}
+
+static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
+                      const int64_t* atom_types, const int64_t* mol_ptr, int64_t n_mol,
+                      int64_t n_nodes, int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                      float* energy, float* forces, void* workspace, int32_t* status, void* stream,
+                      hipEvent_t* ev) {
+  if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0) return FMD_EINVAL;
+  if (n_mol == 0 || n_nodes == 0) return FMD_OK;
+  if (!packed_dev || !pos || !atom_types || !mol_ptr || !energy || !forces || !workspace || !status)
+    return FMD_EINVAL;
+  if (max_beads_per_mol < 1 || max_beads_per_mol > MAX_LDS_ROWS_FS) return FMD_EUNSUPPORTED;
+  // feature-split mode: the split kernels only (fp32-grade default and W16A16)
+  const bool fs = max_beads_per_mol > MAX_LDS_ROWS;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return FMD_EINVAL;
+  hipStream_t s = fmd_stream(stream);
+  const int L = desc->num_blocks;
+  const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
+  if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
+  const int split = fs ? 2 : resolve_split(desc, n_mol);  // FS: the two feature halves
+  const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, split);
+  const PackLayout PL = pack_layout(desc);
+  const float* pk = reinterpret_cast<const float*>(packed_dev);
+
+  int rc = ensure_kernel_attrs();
+  if (rc != FMD_OK) return rc;
+
+  int kidx = 0;  // kernel index in launch order (fmd_schnet_kernel_name)
+  // a NULL slot skips that record: a caller may time a single kernel without paying for 2 records per launch
+  auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
+  auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
+  {
+    PairsArgs pa;
+    pa.pos = pos; pa.mol_ptr = mol_ptr; pa.rc = desc->cutoff; pa.cap = (int)cap; pa.poi = ws.poi; pa.poj = ws.poj;
+    pa.pd = ws.pd; pa.pc = ws.pc; pa.pdc = ws.pdc; pa.npairs = ws.npairs; pa.report = ws.report;
+    pa.max_beads = (int)max_beads_per_mol; pa.forces = forces;
+    ev_begin();
+    rc = launch_pairs(pa, n_mol, s);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+  }
+
+  const bool half = desc->precision == FMD_PREC_W16A16;
+  const int64_t n_tiles = (n_nodes + 31) / 32;
+  // node kernels: one workgroup per CU walks 32-row tiles (the kernels keep their operands in registers)
+  const int64_t cus = device_cus();
+  const unsigned res_grid = (unsigned)(n_tiles < cus ? n_tiles : cus);
+  const int64_t slab_stride = n_nodes * F;
+
+  auto edge = [&](bool fwd, int l) -> int {
+    const BlockOff o = block_off(PL, l);
+    EdgeArgs ea;
+    ea.poi = ws.poi; ea.poj = ws.poj; ea.pd = ws.pd; ea.pc = ws.pc; ea.pdc = ws.pdc; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
+    ea.mol_ptr = mol_ptr; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
+    ea.b0 = pk + o.b0;
+    ea.q0h = pk + o.q0h; ea.q0l = pk + o.q0l; ea.q1h = pk + o.q1h; ea.q1l = pk + o.q1l;
+    ea.q1th = pk + o.q1th; ea.q1tl = pk + o.q1tl;
+    ea.q0ch = pk + o.q0ch; ea.q0cl = pk + o.q0cl; ea.c0 = 0.5f * desc->cutoff; ea.nb = (desc->num_rbf + 7) / 8;
+    ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
+    ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
+    ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
+    if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, n_mol, s);
+    return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, n_mol, s);
+  };
+
+  // ---------------- forward
+  for (int l = 0; l < L; ++l) {
+    const BlockOff o = block_off(PL, l);
+    ev_begin();
+    if (l == 0) {
+      rc = launch_node_embed(atom_types, pk + PL.emb, pk + PL.emb_x1, ws.x, ws.x1[0], n_nodes, s);
+    } else {
+      const BlockOff q = block_off(PL, l - 1);
+      NodeFwdArgs na;
+      na.x = ws.x; na.slabs = ws.slabs; na.slab_stride = slab_stride; na.n_slabs = split;
+      na.l1 = pk + o.l1; na.x1_out = ws.x1[l]; na.n_nodes = n_nodes;
+      na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
+      rc = launch_node_fwd(na, res_grid, s);
+    }
+    ev_end();
+    if (rc != FMD_OK) return rc;
+    ev_begin();
+    rc = edge(true, l);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+  }
+  {
+    const BlockOff q = block_off(PL, L - 1);
+    NodeOutArgs oa;
+    oa.x = ws.x; oa.slabs = ws.slabs; oa.slab_stride = slab_stride; oa.n_slabs = split;
+    oa.l2 = pk + q.l2; oa.b2 = pk + q.b2; oa.l3 = pk + q.l3; oa.b3 = pk + q.b3; oa.t_out = ws.t[L - 1];
+    for (int k = 0; k < 3; ++k) {
+      const int kk = k < desc->num_out ? k : desc->num_out - 1;
+      const float* base = pk + PL.outs + kk * PL.out_stride;
+      oa.po[k] = base; oa.bo[k] = base + SLICE; oa.pot[k] = base + SLICE + F;
+    }
+    oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
+    ev_begin();
+    rc = launch_node_out(oa, desc->num_out, half, res_grid, s);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+  }
+  // ---------------- backward
+  for (int l = L - 1; l >= 0; --l) {
+    const BlockOff o = block_off(PL, l);
+    NodeBwdArgs ba;
+    ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = split;
+    ba.t = ws.t[l]; ba.l3t = pk + o.l3t; ba.l2t = pk + o.l2t; ba.gagg = ws.gagg; ba.n_nodes = n_nodes;
+    ba.l1t = l == L - 1 ? nullptr : pk + block_off(PL, l + 1).l1t;
+    ev_begin();
+    rc = launch_node_bwd(ba, /*has_slabs=*/l != L - 1, res_grid, s);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+    ev_begin();
+    rc = edge(false, l);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+  }
+  {
+    FinishArgs fa;
+    fa.pos = pos; fa.mol_ptr = mol_ptr; fa.poi = ws.poi; fa.poj = ws.poj; fa.pd = ws.pd; fa.pgd = ws.pgd;
+    fa.pgd2 = fs ? ws.pgd + n_mol * cap : nullptr; fa.npairs = ws.npairs; fa.cap = (int)cap; fa.e_node = ws.e_node;
+    fa.energy = energy; fa.forces = forces; fa.max_beads = (int)max_beads_per_mol; fa.report = ws.report;
+    fa.status = status;
+    ev_begin();
+    rc = launch_finish(fa, n_mol, s);
+    ev_end();
+    if (rc != FMD_OK) return rc;
+  }
+  return FMD_OK;
+}
+
+extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void* packed_dev,
+                                        const float* pos, const int64_t* atom_types,
+                                        const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                                        int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                                        float* energy, float* forces, void* workspace,
+                                        int32_t* status, void* stream) {
+  return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
+                    max_pairs_per_mol, energy, forces, workspace, status, stream, nullptr);
+}
+
+extern "C" int fmd_schnet_kernel_count(const fmd_schnet_desc* desc) {
+  return desc_ok(desc) ? 4 * desc->num_blocks + 3 : FMD_EINVAL;
+}
+
+extern "C" const char* fmd_schnet_kernel_name(const fmd_schnet_desc* desc, int idx) {
+  if (!desc_ok(desc) || idx < 0 || idx >= 4 * desc->num_blocks + 3) return "";
+  const int L = desc->num_blocks;
+  if (idx == 0) return "pairs_kernel";
+  if (idx <= 2 * L) return (idx & 1) ? "node_fwd_kernel" : "edge_fwd_kernel";
+  if (idx == 2 * L + 1) return "node_out_kernel";
+  if (idx <= 4 * L + 1) return (idx & 1) ? "edge_bwd_kernel" : "node_bwd_kernel";
+  return "finish_kernel";
+}
+
+extern "C" int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* packed_dev,
+                                              const float* pos, const int64_t* atom_types,
+                                              const int64_t* mol_ptr, int64_t n_mol, int64_t n_nodes,
+                                              int64_t max_beads_per_mol, int64_t max_pairs_per_mol,
+                                              float* energy, float* forces, void* workspace,
+                                              int32_t* status, void* stream, void** events,
+                                              int64_t n_events) {
+  if (!desc_ok(desc) || !events || n_events < 2 * (4 * desc->num_blocks + 3)) return FMD_EINVAL;
+  return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
+                    max_pairs_per_mol, energy, forces, workspace, status, stream,
+                    reinterpret_cast<hipEvent_t*>(events));
+}

@@ -1,0 +1,442 @@
+// Fused engine, first and last launch of a force evaluation: the per-molecule pair list (replaces
+// torch_cluster.radius_graph as called at neighbor_list/torch_impl.py:216-224, for undirected pairs) and the
+// final reduction dE/dd -> forces, per-node energies -> energy[B] (models/gradients.py:265-280, schnet.py:352-357).
+#include "fmd_engine.h"
+
+namespace {
+// ---------------------------------------------------------------------------------------------
+// pair list: undirected i<j, strict d2 < rc2 with unfused fp32, sorted by centre i then j.
+// Each centre's entries are padded to a multiple of 4 (pad = (i,i) with d = rc, whose cutoff is 0), so a
+// 4-entry half of an 8-entry SEGMENT of a 32-entry tile always belongs to one centre, and both halves do
+// unless the rows are disjoint (see the conflict flags below): inside a segment the neighbours j are
+// distinct, which lets the edge kernels accumulate with plain LDS read-modify-write (no float atomics) and
+// one in-register reduction per segment.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ pos,
+                                                    const int64_t* __restrict__ mol_ptr, float rc2,
+                                                    float rc, int cap, uint32_t* __restrict__ poi,
+                                                    uint32_t* __restrict__ poj,
+                                                    float* __restrict__ pd, float* __restrict__ pc,
+                                                    float* __restrict__ pdc, int32_t* __restrict__ npairs,
+                                                    int32_t* __restrict__ report, int max_beads, float* __restrict__ forces, int ent_cap) {
+  // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
+  // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
+  // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t a0 = mol_ptr[m];
+  int n = (int)(mol_ptr[m + 1] - a0);
+  if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
+    n = max_beads;
+  }
+  const bool bad_bound = (int)(mol_ptr[m + 1] - a0) > max_beads;
+  float* sx = smem;
+  float* sy = sx + n;
+  float* sz = sy + n;
+  int* cnt = reinterpret_cast<int*>(sz + n);   // [n]     pairs of row i (j > i)
+  int* rowstart = cnt + n;                      // [n + 1] offset of the row's run
+  int* rowend = rowstart + n + 1;               // [n]     end of the run including its pad entries
+  int* conf = rowend + n;                       // [n]     row i must not share an 8-entry segment with the row before
+  const int NC = (n + 63) >> 6;                 // 64-candidate chunks of a row (at most 9: 535 beads)
+  // [n][NC] hit masks: bit b of masks[i NC + c] <-> (i, 64 c + b) is a pair; chunks below (i + 1) / 64 are not written
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((7 * n + 2) & ~1));
+  __shared__ int tot_s[3];
+  for (int i = tid; i < n; i += 1024) {
+    sx[i] = pos[3 * (a0 + i)];
+    sy[i] = pos[3 * (a0 + i) + 1];
+    sz[i] = pos[3 * (a0 + i) + 2];
+  }
+  // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
+  if (part == 0)
+    for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
+  __syncthreads();
+  auto dist2 = [&](int i, int j) {
+    const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  };
+  // ---- pass 1: the hit masks and row counts.  A lane keeps its candidates j = 64 c + lane in registers (beads
+  //      beyond the molecule sit at 1e30: their d2 is +inf and never a hit), a wave takes one centre row at a time.
+  {
+    float px[9], py[9], pz[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int j = 64 * c + lane;
+      const bool ok = j < n;
+      px[c] = ok ? sx[j] : 1e30f;
+      py[c] = ok ? sy[j] : 1e30f;
+      pz[c] = ok ? sz[j] : 1e30f;
+    }
+    for (int i = wv; i < n; i += 16) {
+      const float xi = sx[i], yi = sy[i], zi = sz[i];
+      const int c_first = (i + 1) >> 6;
+      int c_tot = 0;
+      unsigned mlo = 0u, mhi = 0u;  // lane c collects the mask of chunk c: one LDS store per row
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        if (c >= c_first && c < NC) {
+          const float dx = __fsub_rn(px[c], xi), dy = __fsub_rn(py[c], yi), dz = __fsub_rn(pz[c], zi);
+          const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2);
+          mlo = lane == c ? (unsigned)mk : mlo;
+          mhi = lane == c ? (unsigned)(mk >> 32) : mhi;
+          c_tot += __popcll(mk);
+        }
+      }
+      if (lane < NC) masks[i * NC + lane] = ((unsigned long long)mhi << 32) | mlo;  // (zero below c_first)
+      if (lane == 0) cnt[i] = c_tot;
+    }
+  }
+  __syncthreads();
+  // ---- which rows may share an 8-entry segment with the row before them: the two halves of a segment are
+  //      updated side by side, so the centre and the (at most four) first neighbours of row i must not appear among
+  //      the neighbours in the last group of four of the row before (centres ascend, so they cannot meet otherwise)
+  for (int i = tid; i < n; i += 1024) {
+    bool cf = false;
+    if (cnt[i] > 0) {
+      int p = i - 1;
+      while (p >= 0 && cnt[p] == 0) --p;
+      if (p >= 0) {
+        // the row's first (at most four) neighbours and the last rp of the row before, as 16-bit fields
+        unsigned long long hd = ~0ull, tl = ~0ull;
+        int hn = 0, tn = 0;
+        for (int c = (i + 1) >> 6; c < NC && hn < 4; ++c) {
+          unsigned long long m2 = masks[i * NC + c];
+          while (m2 && hn < 4) {
+            hd = (hd << 16) | (unsigned long long)(64 * c + __ffsll((long long)m2) - 1);
+            m2 &= m2 - 1;
+            ++hn;
+          }
+        }
+        const int rp = ((cnt[p] - 1) & 3) + 1;
+        for (int c = NC - 1; c >= ((p + 1) >> 6) && tn < rp; --c) {
+          unsigned long long m2 = masks[p * NC + c];
+          while (m2 && tn < rp) {
+            const int bt = 63 - __clzll((long long)m2);
+            m2 ^= 1ull << bt;
+            tl = (tl << 16) | (unsigned long long)(64 * c + bt);
+            ++tn;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const unsigned tv = (unsigned)(tl >> (16 * t)) & 0xffffu;  // 0xffff: no such neighbour
+          bool hit = tv == (unsigned)i;
+#pragma unroll
+          for (int y = 0; y < 4; ++y) hit |= tv == ((unsigned)(hd >> (16 * y)) & 0xffffu);
+          cf |= tv != 0xffffu && hit;
+        }
+      }
+    }
+    conf[i] = cf ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- offsets: every run is padded to a multiple of FOUR entries; a run that would start in the second half of
+  //      an 8-entry segment whose first half belongs to a conflicting row is pushed to the next segment (the gap
+  //      becomes pad entries of the row before); the total is padded to a multiple of 8.
+  //      Done by one wave in three short steps instead of one 269-step loop: the only state a row inherits is
+  //      whether it starts in the second half of a segment, so each lane runs its chunk of rows for both start
+  //      states, the chunk functions are composed across lanes by a shuffle scan, and each lane replays its chunk
+  //      from its true start offset.
+  if (wv == 0) {
+    const int chunk = (n + 63) >> 6, lo_r = min(n, lane * chunk), hi_r = min(n, lo_r + chunk);
+    int dl[2], es[2], last_ne = -1, real = 0;
+#pragma unroll
+    for (int s0 = 0; s0 < 2; ++s0) {
+      int st = s0, delta = 0;
+      for (int i = lo_r; i < hi_r; ++i) {
+        const int c = cnt[i];
+        if (c == 0) continue;
+        if (st && conf[i]) { delta += 4; st = 0; }
+        const int pad = (c + 3) & ~3;
+        delta += pad;
+        st ^= (pad >> 2) & 1;
+        if (s0 == 0) { last_ne = i; real += c; }
+      }
+      dl[s0] = delta;
+      es[s0] = st;
+    }
+    // inclusive scan over lanes of the chunk functions  state -> (added entries, end state): earlier lanes first
+    int d0 = dl[0], d1 = dl[1], nx = es[0] | (es[1] << 1), ln = last_ne;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int pd0 = __shfl_up(d0, o, 64), pd1 = __shfl_up(d1, o, 64), pnx = __shfl_up(nx, o, 64);
+      const int pln = __shfl_up(ln, o, 64);
+      if (lane >= o) {
+        const int n0 = pnx & 1, n1 = (pnx >> 1) & 1;  // the earlier part's end states
+        const int c0 = pd0 + (n0 ? d1 : d0), c1 = pd1 + (n1 ? d1 : d0);
+        nx = ((nx >> n0) & 1) | (((nx >> n1) & 1) << 1);
+        d0 = c0;
+        d1 = c1;
+        ln = max(ln, pln);
+      }
+    }
+    int base = __shfl_up(d0, 1, 64), prev = __shfl_up(ln, 1, 64);  // exclusive: what the lanes before this one add
+    if (lane == 0) { base = 0; prev = -1; }
+    int off = base;
+    for (int i = lo_r; i < hi_r; ++i) {
+      const int c = cnt[i];
+      rowstart[i] = off;
+      if (c == 0) continue;
+      if ((off & 4) && conf[i]) off += 4;
+      rowstart[i] = off;
+      if (prev >= 0) rowend[prev] = off;
+      off += (c + 3) & ~3;
+      prev = i;
+    }
+    // totals: the last lane's end state; real pairs summed over the wave
+    int real_w = real;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) real_w += __shfl_xor(real_w, o, 64);
+    if (lane == 63) {
+      const int tot = (off + 7) & ~7;
+      if (prev >= 0) rowend[prev] = tot;
+      rowstart[n] = tot;
+      tot_s[0] = tot;
+      tot_s[1] = real_w;
+    }
+  }
+  __syncthreads();
+  const int total = tot_s[0];
+  // this workgroup's rows [r_lo, r_hi) and entries [k_lo, k_hi): the split row is the first one that starts in the
+  // second half of the list (row offsets ascend)
+  if (tid < 64) {
+    int below = 0;
+    for (int i = tid; i < n; i += 64) below += rowstart[i] < (total >> 1) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+    if (tid == 0) tot_s[2] = below;
+  }
+  __syncthreads();
+  const int r_split = tot_s[2];
+  int r_next = r_split;  // the first non-empty row of the second part: its (final) offset ends the first part's pads
+  while (r_next < n && cnt[r_next] == 0) ++r_next;
+  const int k_split = r_next < n ? rowstart[r_next] : total;
+  const int r_lo = part ? r_split : 0, r_hi = part ? n : r_split;
+  const int k_lo = part ? k_split : 0, k_hi = part ? total : k_split;
+  // ---- pass 2: fill from the masks (sorted by j)
+  uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
+  uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
+  float* d_out = pd + (int64_t)m * cap;
+  float* c_out = pc + (int64_t)m * cap;
+  float* dc_out = pdc + (int64_t)m * cap;
+  // The (centre, neighbour) entries are staged in LDS as i | j << 16 when the list fits (ent_cap entries): the sweep's
+  // scattered writes (a dozen active lanes per store) then stay on chip, and the entry arrays are written once,
+  // densely, by the pass below.  A longer list is written straight to the arrays and read back.
+  uint32_t* ent = reinterpret_cast<uint32_t*>(masks + n * NC);
+  const bool staged = total <= ent_cap;
+  for (int i = r_lo + wv; i < r_hi; i += 16) {
+    if (cnt[i] == 0) continue;
+    int k = rowstart[i];
+    k = __builtin_amdgcn_readfirstlane(k);
+    const unsigned long long mrow = lane < NC ? masks[i * NC + lane] : 0ull;  // lane c: the mask of chunk c
+    const unsigned rlo = (unsigned)mrow, rhi = (unsigned)(mrow >> 32);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      if (c >= ((i + 1) >> 6) && c < NC) {
+        const unsigned lo = __builtin_amdgcn_readlane(rlo, c), hi = __builtin_amdgcn_readlane(rhi, c);
+        const unsigned long long mk = ((unsigned long long)hi << 32) | lo;  // wave-uniform: used as the execution mask
+        if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
+          const int kk = k + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+          if (staged) {
+            ent[kk] = (uint32_t)i | ((uint32_t)(64 * c + lane) << 16);
+          } else if (kk < cap) {
+            oi_out[kk] = (uint32_t)i * (F * 4);
+            oj_out[kk] = (uint32_t)(64 * c + lane) * (F * 4);
+          }
+        }
+        k += __popcll(mk);
+      }
+    }
+    const int kend = rowend[i];  // pad entries (i, i), C = 0: to the next run (at most 3 + 4 of them)
+    if (k + lane < kend) {
+      if (staged) {
+        ent[k + lane] = (uint32_t)i | ((uint32_t)i << 16);
+      } else if (k + lane < cap) {
+        oi_out[k + lane] = (uint32_t)i * (F * 4);
+        oj_out[k + lane] = (uint32_t)i * (F * 4);
+      }
+    }
+  }
+  __syncthreads();  // (workgroup-scope release/acquire of the entries written above)
+  // ---- distances and cutoff values, one entry per lane (in a candidate sweep only one lane in five holds a pair,
+  //      so sqrt / sin / cos there would run at a fifth of the lanes)
+  for (int k = k_lo + tid; k < min(k_hi, cap); k += 1024) {
+    int i, j;
+    if (staged) {
+      const uint32_t e = ent[k];
+      i = (int)(e & 0xffffu);
+      j = (int)(e >> 16);
+      oi_out[k] = (uint32_t)i * (F * 4);
+      oj_out[k] = (uint32_t)j * (F * 4);
+    } else {
+      i = (int)(oi_out[k] / (F * 4));
+      j = (int)(oj_out[k] / (F * 4));
+    }
+    float d = rc, C = 0.f, dC = 0.f;
+    if (i != j) {
+      d = sqrtf(dist2(i, j));
+      fmd_cutoff2(d, rc, C, dC);
+    }
+    d_out[k] = d;
+    c_out[k] = C;
+    dc_out[k] = dC;
+  }
+  // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
+  // need a validity test
+  if (part == 1) {
+    const int tot_c = min(total, cap) & ~7;
+    const int tot32 = min((tot_c + 31) & ~31, cap);
+    for (int k = tot_c + tid; k < tot32; k += 1024) {
+      oi_out[k] = 0u;
+      oj_out[k] = 0u;
+      d_out[k] = rc;
+      c_out[k] = 0.f;
+      dc_out[k] = 0.f;
+    }
+  }
+  // per-molecule report (error code, entries needed, real pairs): finish_kernel reduces it into the status words,
+  // so nothing has to be zeroed before the call
+  if (part == 0 && tid == 0) {
+    npairs[m] = min(total, cap) & ~7;
+    report[3 * m] = bad_bound ? FMD_EINVAL : (total > cap ? FMD_ECAPACITY : 0);
+    report[3 * m + 1] = total;
+    report[3 * m + 2] = tot_s[1];
+  }
+}
+
+
+// two workgroups (4 waves each) per molecule, each with half of its pair list: forces from dE/dd of the pairs,
+// energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered
+// inside one wave) and the four copies are added in fixed order; the two workgroups then add their halves to
+// the force array that pairs_kernel zeroed: two addends commute, so the result is reproducible.
+__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
+                                                     const int64_t* __restrict__ mol_ptr,
+                                                     const uint32_t* __restrict__ poi,
+                                                     const uint32_t* __restrict__ poj,
+                                                     const float* __restrict__ pd,
+                                                     const float* __restrict__ pgd,
+                                                     const float* __restrict__ pgd2,  // FS: second slab or null
+                                                     const int32_t* __restrict__ npairs, int cap,
+                                                     const float* __restrict__ e_node,
+                                                     float* __restrict__ energy,
+                                                     float* __restrict__ forces, int max_beads,
+                                                     const int32_t* __restrict__ report,
+                                                     int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t a0 = mol_ptr[m];
+  const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
+  float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos
+  __shared__ float esum[4];
+  for (int i = tid; i < 12 * n; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  const int np = npairs[m];
+  const int np_half = ((np + 15) >> 4) << 3;  // the first workgroup's share (whole 8-entry segments)
+  const int q_lo = half ? min(np, np_half) : 0, q_hi = half ? np : min(np, np_half);
+  // every thread walks a contiguous run of the (centre-sorted) list: the centre's contribution is
+  // summed in registers and flushed when the centre changes, so lanes rarely collide in LDS
+  const int chunk = (q_hi - q_lo + 255) / 256;
+  const int p_lo = min(q_hi, q_lo + tid * chunk), p_hi = min(q_hi, p_lo + chunk);
+  int ci = -1;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int p = p_lo; p < p_hi; ++p) {
+    const int i = (int)(poi[(int64_t)m * cap + p] / (F * 4));
+    const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
+    if (i != ci) {
+      if (ci >= 0) {
+        atomicAdd(&g[3 * ci], cx);
+        atomicAdd(&g[3 * ci + 1], cy);
+        atomicAdd(&g[3 * ci + 2], cz);
+      }
+      ci = i;
+      cx = cy = cz = 0.f;
+    }
+    if (i != j) {  // pad entries carry nothing
+      const float d = fmaxf(pd[(int64_t)m * cap + p], 1e-8f);
+      const float gdd = pgd[(int64_t)m * cap + p] + (pgd2 ? pgd2[(int64_t)m * cap + p] : 0.f);
+      const float s = gdd / d;
+      const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
+      const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
+      const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
+      atomicAdd(&g[3 * j], dx);
+      atomicAdd(&g[3 * j + 1], dy);
+      atomicAdd(&g[3 * j + 2], dz);
+      cx -= dx;
+      cy -= dy;
+      cz -= dz;
+    }
+  }
+  if (ci >= 0) {
+    atomicAdd(&g[3 * ci], cx);
+    atomicAdd(&g[3 * ci + 1], cy);
+    atomicAdd(&g[3 * ci + 2], cz);
+  }
+  if (half == 0) {
+    float e = 0.f;
+    for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
+    e = fmd_wave_sum(e);
+    if (lane == 0) esum[wv] = e;
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * n; i += 256)
+    unsafeAtomicAdd(&forces[3 * a0 + i], -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]));
+  if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
+  // the call's status words from pairs_kernel's per-molecule reports (one wave of the first workgroup; a bead-bound
+  // violation outranks a capacity overflow)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) {
+    int err = 0, need = 0, real = 0;
+    for (int q = lane; q < (int)gridDim.y; q += 64) {
+      const int e = report[3 * q];
+      err = (e == FMD_EINVAL || err == FMD_EINVAL) ? FMD_EINVAL : (e != 0 ? e : err);
+      need = max(need, report[3 * q + 1]);
+      real += report[3 * q + 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int e = __shfl_xor(err, o, 64);
+      err = (e == FMD_EINVAL || err == FMD_EINVAL) ? FMD_EINVAL : (e != 0 ? e : err);
+      need = max(need, __shfl_xor(need, o, 64));
+      real += __shfl_xor(real, o, 64);
+    }
+    if (lane == 0) {
+      status[0] = err;
+      status[1] = need;
+      status[2] = real;
+      status[3] = 0;
+    }
+  }
+}
+
+}  // namespace
+
+namespace fmd_eng {
+
+constexpr size_t LDS_PAIRS_MAX = 128 * 1024;
+
+int setup_pairs_attrs() {
+  return hipFuncSetAttribute((const void*)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)LDS_PAIRS_MAX) == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+}
+
+int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s) {
+  // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads), then the entry staging
+  // area: as much of the worst-case list as fits in 128 KB (the list of a 1ENH-sized molecule takes 32 KB)
+  const int64_t nb = a.max_beads;
+  const size_t base = (size_t)(7 * nb + 2 + 2 * ((nb + 63) / 64) * nb) * sizeof(float);
+  const size_t lds = base + (size_t)a.cap * 4 < LDS_PAIRS_MAX ? base + (size_t)a.cap * 4 : LDS_PAIRS_MAX;
+  const int ent_cap = (int)((lds - base) / 4);
+  pairs_kernel<<<dim3(2, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol_ptr, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
+                                                           a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
+                                                           a.forces, ent_cap);
+  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+}
+
+int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s) {
+  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(float), s>>>(
+      a.pos, a.mol_ptr, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
+      a.report, a.status);
+  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+}
+
+}  // namespace fmd_eng

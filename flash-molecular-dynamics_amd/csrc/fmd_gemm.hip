@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const void* __restrict__ 
           const float g = (AK == AK_DTANH_F16G) ? (float)reinterpret_cast<const _Float16*>(Ap)[idx]
                                                  : reinterpret_cast<const float*>(Ap)[idx];
           const float y = (float)reinterpret_cast<const _Float16*>(Yp)[idx];
-          v = g * (1.0f - y * y);
+          // the reference forms g * (1 - y*y) with separately rounded fp32 operations before the fp16
+          // rounding (cfconv_kernels.py:1019-1023); an fma contraction here moves fp16 rounding boundaries
+          v = __fmul_rn(g, __fsub_rn(1.0f, __fmul_rn(y, y)));
         }
       }
       As[r * G16_LD + c] = (_Float16)v;

@@ -42,8 +42,6 @@ SIGNATURES = {
     "fmd_schnet_kernel_count": (I32, [P]),
     "fmd_schnet_kernel_name": (ctypes.c_char_p, [P, I32]),
     "fmd_schnet_energy_forces_timed": (I32, [P, P, P, P, P, I64, I64, I64, I64, P, P, P, P, P, P, I64]),
-    "fmd_debug_set_stamp_buffer": (I32, [P]),
-    "fmd_debug_set_stamp_buffer_bwd": (I32, [P]),
     "fmd_langevin_pre": (I32, [P, P, P, P, P, P, I64, F32, F32, F32, P]),
     "fmd_langevin_post": (I32, [P, P, P, I64, F32, P]),
     "fmd_verlet_pre": (I32, [P, P, P, P, I64, F32, P]),
@@ -101,6 +99,10 @@ def ptr(t):
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def strerror(rc: int) -> str:
+    return lib().fmd_strerror(int(rc)).decode()
 
 
 def check(rc: int, what: str):

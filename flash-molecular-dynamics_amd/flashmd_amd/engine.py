@@ -22,10 +22,10 @@ from . import _ffi
 from ._ffi import call, ptr, stream
 
 MAX_BEADS = 535   # 283 with the whole aggregate in one workgroup's LDS, 535 in feature-split mode
-# fmd_schnet_desc.precision (include/flashmd_hip.h): both are fp32-grade (2e-7 per contraction)
-PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, the fast default
-              "w16a16": 1,     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
-              "f32_mfma": 2}   # FMD_PREC_F32_MFMA: exact fp32 MFMA kernels
+# fmd_schnet_desc.precision (include/flashmd_hip.h)
+PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, fp32-grade (2e-7 per contraction), the default
+              "w16a16": 1}     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
+STATUS_CHECK_EVERY = 1024      # force evaluations between two reads of the device status words (one sync each)
 
 
 def _linears(mlp):
@@ -63,7 +63,7 @@ class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
     def __init__(self, model, n_split: int = 0, precision: Optional[str] = None):
-        """``precision``: "f32" (default), "f32_mfma" or "w16a16"; a model whose filter and output networks
+        """``precision``: "f32" (default) or "w16a16"; a model whose filter and output networks
         were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself."""
         from .schnet import CosineCutoff, GaussianBasis
 
@@ -143,6 +143,8 @@ class FusedSchNetEngine:
         self._ws = None
         self._ws_key = None
         self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._bound_key = None      # (mol_ptr identity) whose caller-supplied bead bound has been validated
+        self._since_check = 0       # force evaluations since the status words were last read
 
     def _workspace(self, n_mol, n_nodes, cap):
         key = (n_mol, n_nodes, cap)
@@ -168,8 +170,18 @@ class FusedSchNetEngine:
         pos = pos.detach()
         assert pos.dtype == torch.float32 and pos.is_contiguous() and atom_types.dtype == torch.int64
         n_nodes, n_mol = pos.shape[0], mol_ptr.numel() - 1
-        if max_beads_per_mol <= 0:  # one host sync, only when the caller did not say
-            max_beads_per_mol = int((mol_ptr[1:] - mol_ptr[:-1]).max().item()) if n_mol else 1
+        # a caller-supplied bound is validated once per batch layout (one host sync); without a bound the true
+        # maximum is computed on every call (one sync each: pass the bound in a time loop)
+        key = (mol_ptr.data_ptr(), mol_ptr.numel(), mol_ptr._version, int(max_beads_per_mol))
+        fresh = key != self._bound_key
+        if max_beads_per_mol <= 0 or fresh:
+            true_max = int((mol_ptr[1:] - mol_ptr[:-1]).max().item()) if n_mol else 1
+            if max_beads_per_mol <= 0:
+                max_beads_per_mol = true_max
+            elif true_max > max_beads_per_mol:
+                raise ValueError(f"fused engine: max_beads_per_mol={max_beads_per_mol} but the batch holds a molecule "
+                                 f"of {true_max} beads")
+            self._bound_key = key
         if max_beads_per_mol > MAX_BEADS:
             raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {MAX_BEADS}")
         # every pair plus <= 7 pad entries per centre (8-entry segments): can never overflow
@@ -184,7 +196,25 @@ class FusedSchNetEngine:
             call("fmd_schnet_energy_forces", *args)
         else:
             call("fmd_schnet_energy_forces_timed", *args, events, len(events))
+        # the device status words: read on the first evaluation of a batch layout and then every
+        # STATUS_CHECK_EVERY evaluations (callers with a natural sync point -- save / export / exchange
+        # intervals -- call check_status() there as well)
+        if fresh or self._since_check >= STATUS_CHECK_EVERY:
+            self.check_status()
+        else:
+            self._since_check += 1
         return energy, forces
+
+    def check_status(self):
+        """Read status[0..3] (one device sync) and raise if the last evaluation flagged a problem
+        (include/flashmd_hip.h: FMD_ECAPACITY = pair list too small, FMD_EINVAL = a molecule larger than
+        max_beads_per_mol was truncated: the results are meaningless)."""
+        self._since_check = 0
+        st = self.status.tolist()
+        if st[0] != 0:
+            raise RuntimeError(f"fused engine: device status {st[0]} ({_ffi.strerror(st[0])}); max pairs seen in "
+                               f"one molecule {st[1]}, total pairs {st[2]}: energies and forces of that call are invalid")
+        return st
 
 
 def maybe_engine(model, data):
@@ -209,5 +239,13 @@ def maybe_engine(model, data):
         mb = int((ptr_[1:] - ptr_[:-1]).max().item())
         data.max_beads_per_mol = mb
     if mb > MAX_BEADS:
+        return None
+    # the engine always builds the full within-cutoff graph: a model whose max_num_neighbors could truncate it, or
+    # a batch that brings its own compatible neighbour list (reference models/schnet.py:216-245, 371-380), goes to
+    # the operator path, which honours both
+    if int(getattr(model, "max_num_neighbors", 1000)) < mb - 1:
+        return None
+    nl = getattr(data, "neighbor_list", None)
+    if nl and model.is_nl_compatible(nl.get(model.name)):
         return None
     return eng

@@ -96,6 +96,7 @@ class StaticPriors:
     def __init__(self, terms: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], max_beads: int):
         self.terms, self.max_beads = terms, int(max_beads)
         self.status = None
+        self._checked = False
 
     @classmethod
     def from_tables(cls, spec: Dict[str, Tuple[Dict[str, torch.Tensor], torch.Tensor]], types, mol_ptr):
@@ -145,7 +146,18 @@ class StaticPriors:
             call("fmd_prior_energy_forces", ptr(pos), ptr(mol_ptr), n_mol, self.max_beads, KIND[kind], ptr(mapping),
                  ptr(params), params.shape[0], ptr(bead_ptr), ptr(entries), mapping.shape[1], ptr(energy),
                  ptr(forces), ptr(self.status), stream())
+        if not self._checked:   # first evaluation: one sync to catch a wrong bead bound / foreign term early
+            self.check_status()
         return energy, forces
+
+    def check_status(self):
+        """status[3] (device): bit 0 = a term reaches outside its molecule, bit 1 = a molecule has more beads than
+        ``max_beads`` (the kernels skipped it).  One sync; raises when either is set."""
+        self._checked = True
+        flag = int(self.status[3])
+        if flag:
+            raise RuntimeError(f"StaticPriors: device status {flag} (1 = term outside its molecule, 2 = molecule "
+                               f"larger than max_beads={self.max_beads}): prior energies/forces are invalid")
 
     def energy_forces(self, pos, mol_ptr):
         energy = torch.zeros(mol_ptr.numel() - 1, dtype=torch.float32, device=pos.device)
@@ -185,4 +197,11 @@ def sum_out(force_fns):
             obj.add_energy_forces(pos, mol_ptr, energy, forces)
         return energy, forces
 
+    def check_status():
+        for f in [first] + [obj for obj, _ in rest]:
+            chk = getattr(f, "check_status", None) or getattr(getattr(f, "__self__", None), "check_status", None)
+            if chk is not None:
+                chk()
+
+    fn.check_status = check_status
     return fn

@@ -224,9 +224,35 @@ class SchNet(torch.nn.Module):
         self._cached_gamma = None
         self._engine = None
 
-    # -- neighbour list: rebuilt every forward, like the reference does in practice
+    def is_nl_compatible(self, nl) -> bool:
+        """reference models/schnet.py:371-380 (+ neighbor_list/neighbor_list.py:131-163): a neighbour list the
+        batch brings along is used when it is an order-2 list without self interaction at this model's cutoff."""
+        if not isinstance(nl, dict):
+            return False
+        need = {"tag": str, "order": int, "index_mapping": torch.Tensor, "cell_shifts": torch.Tensor,
+                "rcut": float, "self_interaction": bool}
+        if not all(isinstance(nl.get(k), t) for k, t in need.items()):
+            return False
+        return nl["order"] == 2 and nl["self_interaction"] is False \
+            and nl["rcut"] == self.rbf_layer.cutoff.cutoff_upper
+
+    # -- neighbour list: a compatible list of the batch is used as it is (reference :216-245); otherwise it is
+    #    rebuilt every forward, like the reference does in practice (SURVEY F3)
     def _edges(self, data, cutoff: float) -> torch.Tensor:
+        nl = getattr(data, "neighbor_list", None)
+        nl = nl.get(self.name) if nl else None
+        if self.is_nl_compatible(nl):
+            return nl["index_mapping"]
         ptr = _mol_ptr(data)
+        mb = int(getattr(data, "max_beads_per_mol", 0))
+        if mb <= 0:
+            mb = int((ptr[1:] - ptr[:-1]).max().item()) if ptr.numel() > 1 else 1
+        if self.max_num_neighbors < mb - 1:
+            # torch_cluster would keep an implementation-defined subset of max_num_neighbors neighbours
+            # (neighbor_list/torch_impl.py:216-224); this build has no such truncation and refuses to guess
+            raise NotImplementedError(
+                f"max_num_neighbors={self.max_num_neighbors} can truncate the neighbourhoods of a {mb}-bead "
+                "molecule; the MI355X path builds the full within-cutoff graph only")
         if any_hip_gate_on():
             _need_gpu(data.pos, "SchNet neighbour list")
             return K.radius_graph(data.pos, cutoff, data.batch, ptr_=ptr,
@@ -302,7 +328,8 @@ class GradientsOut(torch.nn.Module):
     def forward(self, data):
         eng = engine_for(self.model, data)
         if eng is not None:  # fused HIP engine: energy and forces in one pass, no autograd graph
-            energy, forces = eng.energy_forces(data.pos, data.atom_types, _mol_ptr(data))
+            energy, forces = eng.energy_forces(data.pos, data.atom_types, _mol_ptr(data),
+                                               int(getattr(data, "max_beads_per_mol", 0)))
             data.out[self.name] = {ENERGY_KEY: energy, FORCE_KEY: forces}
             data.pos = data.pos.detach()
             return data

@@ -126,7 +126,17 @@ class LangevinSimulation:
         rate = (n_timesteps - half) * self.n_sims / (time.perf_counter() - t0)
         if writer is not None:
             writer.close()
+        self.check_status()
         return rate
+
+    def check_status(self):
+        """Read the device status words of the force providers (a sync; called where one happens anyway: end of a
+        run, chunk export, exchange bookkeeping).  ``force_fn`` may expose ``check_status()`` itself (SumForces does)
+        or be a bound method of an object that does (FusedSchNetEngine.energy_forces)."""
+        fn = getattr(self.force_fn, "check_status", None) or getattr(getattr(self.force_fn, "__self__", None),
+                                                                     "check_status", None)
+        if fn is not None:
+            fn()
 
     def kinetic_energy(self):
         """per molecule, 0.5 sum m v^2 (reference simulation/langevin.py:266-271)"""
@@ -201,6 +211,7 @@ class TrajectoryWriter:
         import numpy as np
 
         self._join()
+        sim.check_status()
         key = f"{self.index:04d}"
         out = {"coords": self.coords}
         if self.save_forces:
@@ -284,9 +295,18 @@ class NVESimulation(LangevinSimulation):
 
 def pt_pairs(n_betas: int, even: bool):
     """Neighbouring temperature pairs proposed in one exchange attempt: (0,1),(2,3).. on even
-    attempts, (1,2),(3,4).. on odd ones (reference simulation/parallel_tempering.py:256-284,349-366)."""
-    start = 0 if even else 1
-    return [(a, a + 1) for a in range(start, n_betas - 1, 2)]
+    attempts, (1,2),(3,4).. on odd ones; with two temperatures there is no odd pair and the reference
+    proposes (0,1) every time (reference simulation/parallel_tempering.py:256-284,349-366)."""
+    odd = [(a, a + 1) for a in range(1, n_betas - 1, 2)]
+    evn = [(a, a + 1) for a in range(0, n_betas - 1, 2)]
+    return evn if (even or not odd) else odd
+
+
+def pt_count(matrix: torch.Tensor, a: int, b: int, approved: int, n_indep: int):
+    """The reference's symmetric acceptance matrix (parallel_tempering.py:99-104,407-412): entry [a][b] (a < b)
+    accumulates the accepted exchanges of the temperature pair, entry [b][a] the rejected ones."""
+    matrix[a, b] += approved
+    matrix[b, a] += n_indep - approved
 
 
 def pt_accept(u_a, u_b, beta_a: float, beta_b: float, rand_u):
@@ -318,8 +338,10 @@ class DistributedReplicaExchange:
         self.betas = [float(b) for b in betas]
         self.n_indep, self.n_atoms, self.seed = n_indep, n_atoms, seed
         self.attempt = 0
-        self.accepted = torch.zeros(self.world, dtype=torch.int64)   # with the upper neighbour
-        self.attempted = torch.zeros(self.world, dtype=torch.int64)
+        # this rank's share of the acceptance matrix: the lower rank of a pair counts for the pair
+        self.local_matrix = torch.zeros(self.world, self.world, dtype=torch.int64)
+        self.exchange_seconds = 0.0   # wall time spent inside exchange attempts that had a partner
+        self.exchanges = 0
 
     def partner(self, even: bool) -> Optional[int]:
         for a, b in pt_pairs(self.world, even):
@@ -330,12 +352,15 @@ class DistributedReplicaExchange:
         return None
 
     def __call__(self, sim: "LangevinSimulation"):
+        import time
+
         even = self.attempt % 2 == 0
         peer = self.partner(even)
         attempt = self.attempt
         self.attempt += 1
-        if peer is None:
+        if peer is None:      # an end rank sits this phase out (odd phase: ranks 0 and W-1 for even W)
             return
+        t0 = time.perf_counter()
         dist = self.dist
         lo, hi = min(self.rank, peer), max(self.rank, peer)
         # 1. energies of the partner's replicas
@@ -349,34 +374,49 @@ class DistributedReplicaExchange:
         rand_u = torch.rand(self.n_indep, generator=g).to(u_mine.device)
         u_a, u_b = (u_mine, u_peer) if self.rank == lo else (u_peer, u_mine)
         acc = pt_accept(u_a, u_b, self.betas[lo], self.betas[hi], rand_u)
-        # 3. positions and velocities of the whole batch cross the link once, each way
-        payload = torch.stack([sim.x, sim.v]).contiguous()
-        incoming = torch.empty_like(payload)
-        ops = [dist.P2POp(dist.isend, payload, peer, self.group), dist.P2POp(dist.irecv, incoming, peer, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
-        #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
-        mask = acc.repeat_interleave(self.n_atoms)[:, None]
-        scale = math.sqrt(self.betas[self.rank] / self.betas[peer])
-        sim.x = torch.where(mask, incoming[0], sim.x).contiguous()
-        sim.v = torch.where(mask, incoming[1] * scale, sim.v).contiguous()
+        n_acc = int(acc.sum())   # one host sync per attempt, identical on both partners
         if self.rank == lo:
-            self.accepted[lo] += int(acc.sum())
-            self.attempted[lo] += self.n_indep
-        # forces/energies of the swapped replicas belong to the other temperature's coordinates:
-        # re-evaluate so the next B half-kick uses forces at the new positions (the reference keeps
-        # stale forces until the next timestep's force call; re-evaluating is the conservative choice)
-        sim.energy, sim.f = sim.force_fn(sim.x)
+            pt_count(self.local_matrix, lo, hi, n_acc, self.n_indep)
+        if n_acc:
+            # 3. positions and velocities of the whole batch cross the link once, each way
+            payload = torch.stack([sim.x, sim.v]).contiguous()
+            incoming = torch.empty_like(payload)
+            ops = [dist.P2POp(dist.isend, payload, peer, self.group),
+                   dist.P2POp(dist.irecv, incoming, peer, self.group)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
+            #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
+            mask = acc.repeat_interleave(self.n_atoms)[:, None]
+            scale = math.sqrt(self.betas[self.rank] / self.betas[peer])
+            sim.x = torch.where(mask, incoming[0], sim.x).contiguous()
+            sim.v = torch.where(mask, incoming[1] * scale, sim.v).contiguous()
+            # forces/energies of the swapped replicas belong to the other temperature's coordinates:
+            # re-evaluate so the next B half-kick uses forces at the new positions (the reference keeps
+            # stale forces until the next timestep's force call; re-evaluating is the conservative choice).
+            # Nothing accepted: nothing moved, nothing to re-evaluate.
+            sim.energy, sim.f = sim.force_fn(sim.x)
+        self.exchange_seconds += time.perf_counter() - t0
+        self.exchanges += 1
+
+    def acceptance_matrix(self):
+        """The reference's [n_betas, n_betas] matrix (accepted above the diagonal, rejected below) summed over
+        ranks; a collective, for export time only (reference parallel_tempering.py:504-517 writes it to
+        ``{filename}_acceptance_XXXX.npy`` and resets it)."""
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        m = self.local_matrix.to(dev)
+        self.dist.all_reduce(m, group=self.group)
+        return m.cpu()
+
+    def reset_acceptance(self):
+        self.local_matrix.zero_()
 
     def acceptance(self):
-        """Per-pair acceptance counts reduced to every rank (export-time only)."""
-        acc, att = self.accepted.clone(), self.attempted.clone()
-        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
-        acc, att = acc.to(dev), att.to(dev)
-        self.dist.all_reduce(acc, group=self.group)
-        self.dist.all_reduce(att, group=self.group)
-        return acc.cpu(), att.cpu()
+        """(accepted[k], attempted[k]) of the pair (k, k+1), every rank."""
+        m = self.acceptance_matrix()
+        acc = torch.tensor([int(m[k, k + 1]) for k in range(self.world - 1)] + [0])
+        rej = torch.tensor([int(m[k + 1, k]) for k in range(self.world - 1)] + [0])
+        return acc, acc + rej
 
 
 class LocalReplicaExchange:
@@ -388,6 +428,7 @@ class LocalReplicaExchange:
         self.betas, self.n_indep, self.n_atoms = [float(b) for b in betas], n_indep, n_atoms
         self.gen = torch.Generator().manual_seed(seed)
         self.attempt = 0
+        self.acceptance_matrix = torch.zeros(len(self.betas), len(self.betas), dtype=torch.int64)
 
     def __call__(self, sim: "LangevinSimulation"):
         even = self.attempt % 2 == 0
@@ -402,5 +443,9 @@ class LocalReplicaExchange:
         beta = sim.beta_mol
         p = torch.exp((sim.energy[mol_a] - sim.energy[mol_b]) * (beta[mol_a] - beta[mol_b]))
         acc = (torch.rand(p.numel(), generator=self.gen).to(dev) < p).to(torch.uint8)
-        pt_swap_local(sim.x, sim.v, mol_a, mol_b, acc, beta, self.n_atoms)
-        sim.energy, sim.f = sim.force_fn(sim.x)
+        per_pair = acc.view(len(pairs), self.n_indep).sum(1).tolist()   # one host sync per attempt
+        for (a, b), n_acc in zip(pairs, per_pair):
+            pt_count(self.acceptance_matrix, a, b, int(n_acc), self.n_indep)
+        if sum(per_pair):
+            pt_swap_local(sim.x, sim.v, mol_a, mol_b, acc, beta, self.n_atoms)
+            sim.energy, sim.f = sim.force_fn(sim.x)

@@ -11,7 +11,9 @@
  *   - nothing is allocated inside: the caller passes outputs and (where named) a workspace;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
  *   - return 0 on success, a negative FMD_E* code otherwise (fmd_strerror gives the text);
- *     no exceptions, no global state.
+ *     no exceptions, and no state a caller can observe: the library holds no buffers, reads no
+ *     environment variables and keeps nothing between calls except a per-device "kernel attributes are
+ *     set" flag (the dynamic-LDS ceiling of its own kernels, raised once, idempotent).
  */
 #ifndef FLASHMD_HIP_H
 #define FLASHMD_HIP_H
@@ -153,14 +155,13 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
  *   Weights are packed once by fmd_schnet_pack_bytes / fmd_schnet_pack (device buffer).
  *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as
  *   fp16 hi + lo/2048 and a.b = hi.hi + (hi.lo + lo.hi)/2048 on v_mfma_f32_32x32x16_f16 with fp32
- *   accumulation -- relative error 2e-7, the same as fp32 MFMA, at 3/16 of its MFMA cycles) or
- *   FMD_PREC_F32_MFMA (exact fp32 products); FMD_PREC_W16A16 = the reference's W16A16 mode
+ *   accumulation -- relative error 2e-7, the same as fp32 MFMA, at 3/16 of its MFMA cycles);
+ *   FMD_PREC_W16A16 = the reference's W16A16 mode
  *   (models/gptq.py:92-130,266-306): filter and output networks with fp16 operands (weights =
  *   Linear.weight.half(), activations rounded to fp16 where they are stored), fp32 accumulation.
  * ------------------------------------------------------------------------------------------- */
 #define FMD_PREC_F32 0        /* fp32 results: fp16 hi/lo split operands on the fp16 MFMA, fp32 accumulate */
 #define FMD_PREC_W16A16 1     /* filter and output networks: fp16 operands and stored activations, fp32 accumulate */
-#define FMD_PREC_F32_MFMA 2   /* fp32 results: exact fp32 products on v_mfma_f32_32x32x2_f32 */
 
 typedef struct fmd_schnet_desc {
   int32_t hidden;        /* = num_filters = 128 */
@@ -206,8 +207,8 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
  * [2] = total pairs, [3] reserved (0). All four words are written by the call's last kernel (nothing has to be
  * zeroed beforehand); read them back at the caller's convenience.  forces / energy are fully overwritten. */
 /* max_beads_per_mol: upper bound on beads of one molecule.  The per-molecule aggregate lives in LDS: up to 283
- * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each;
- * FMD_PREC_F32 and FMD_PREC_W16A16 only).  Larger molecules return FMD_EUNSUPPORTED and take the operator path.
+ * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each).
+ * Larger molecules return FMD_EUNSUPPORTED and take the operator path.
  * max_pairs_per_mol: capacity of the per-molecule pair list, whose per-centre runs are padded to
  *   multiples of 4 entries (plus at most one 4-entry group per run and 7 at the end); A(A-1)/2 + 8A can never
  *   overflow.
@@ -232,12 +233,6 @@ int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const void* pack
                                    int64_t max_pairs_per_mol, float* energy, float* forces,
                                    void* workspace, int32_t* status, void* stream, void** events,
                                    int64_t n_events);
-
-/* Diagnostics only: device buffer [workgroups][4][6] of uint64 receiving per-phase cycle totals from
- * the stamped build of the forward pair kernel (NULL restores the normal kernels). */
-int fmd_debug_set_stamp_buffer(void* device_buffer);
-/* same for the backward pair kernel of the middle blocks: [workgroups][4][16] uint64 */
-int fmd_debug_set_stamp_buffer_bwd(void* device_buffer);
 
 /* ---------------------------------------------------------------------------------------------
  * Row N1: Langevin BAOAB elementwise halves around the force call (simulation/langevin.py:136-170).

@@ -146,26 +146,15 @@ def test_fused_engine_is_the_path_taken_and_deterministic(params):
         assert _relerr(e3, f3, e_o.numpy(), f_o.numpy())[1] < 1e-4
 
 
-def test_fused_engine_exact_fp32_mfma_kernels(params, golden_dir):
-    """precision="f32_mfma" (FMD_PREC_F32_MFMA): the exact-fp32 MFMA kernels meet the same budget and agree
-    with the split-operand default to fp32 rounding."""
+def test_fused_engine_rejects_unknown_precision(params):
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
-    z = np.load(os.path.join(golden_dir, "case_1enh_2x269.npz"))
-    pos, types, ptr = (torch.from_numpy(z[k]).to(DEV) for k in ("pos", "types", "ptr"))
     model = S.model_from_params(params).to(DEV)
-    out = {}
-    for prec in ("f32", "f32_mfma"):
-        e, f = engine.FusedSchNetEngine(model, precision=prec).energy_forces(pos, types, ptr, 269)
-        re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
-        print(f"precision={prec}: energy {re:.2e} forces {rf:.2e}")
-        assert re < 2e-5 and rf < 2e-5
-        out[prec] = (e, f)
-    rf = float((out["f32"][1] - out["f32_mfma"][1]).norm() / out["f32_mfma"][1].norm())
-    assert rf < 1e-5
     with pytest.raises(ValueError):
         engine.FusedSchNetEngine(model, precision="bf16")
+    with pytest.raises(ValueError):
+        engine.FusedSchNetEngine(model, precision="f32_mfma")  # retired in round 2
 
 
 def test_fused_engine_other_hyperparameters():
@@ -400,21 +389,57 @@ def test_feature_split_mode_properties(params, precision):
     assert re < (2e-3 if w16 else 1e-4) and rf < (2e-3 if w16 else 1e-4)
 
 
-def test_wrong_bead_bound_is_flagged_not_faulted(params):
-    """A caller that understates max_beads_per_mol gets status[0] = FMD_EINVAL (and no out-of-bounds LDS access: the
-    kernels truncate the molecule to the bound the LDS was sized for); with the right bound the same engine works."""
+def test_wrong_bead_bound_raises_and_device_flag_is_read(params):
+    """A caller that understates max_beads_per_mol is refused on the host (validated once per batch layout), also
+    through the reference-shaped entry GradientsOut(Batch(max_beads_per_mol=...)).  Underneath, the kernels truncate
+    such a molecule to the bound the LDS was sized for (no out-of-bounds access) and set status[0] = FMD_EINVAL, which
+    check_status() turns into an error; with the right bound the same engine works."""
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
     pos, types, ptr = so.synth_batch(2, 60, 5.0)
-    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    model = S.model_from_params(params).to(DEV)
+    eng = engine.FusedSchNetEngine(model)
     P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
-    eng.energy_forces(P, T, Q, 40)          # wrong: the molecules have 60 beads
-    assert int(eng.status[0]) == -1
+    with pytest.raises(ValueError):
+        eng.energy_forces(P, T, Q, 40)          # wrong: the molecules have 60 beads
+    S.USE_FUSED_ENGINE = True
+    with pytest.raises(ValueError):
+        S.GradientsOut(model).eval()(S.Batch(P, T, Q, max_beads_per_mol=40))
+    # the device-side flag, reached by skipping the host validation
+    eng._bound_key = (Q.data_ptr(), Q.numel(), Q._version, 40)
+    eng.energy_forces(P, T, Q, 40)
+    with pytest.raises(RuntimeError):
+        eng.check_status()
     e, f = eng.energy_forces(P, T, Q, 60)
-    assert int(eng.status[0]) == 0
+    assert eng.check_status()[0] == 0
     e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
     assert _relerr(e, f, e_o.numpy(), f_o.numpy())[1] < 1e-4
+
+
+def test_neighbour_list_semantics_of_the_reference(params):
+    """reference models/schnet.py:216-245: a compatible neighbour list of the batch is used as it is, and
+    max_num_neighbors truncates; the engine (full graph only) steps aside for the first and the path refuses the
+    second instead of silently computing something else."""
+    import flashmd_amd.schnet as S
+
+    pos, types, ptr = so.synth_batch(2, 40, 5.0)
+    src, dst = so.radius_graph(pos, ptr, 5.0)
+    keep = torch.arange(src.numel()) % 3 != 0   # a thinned list: the result must follow IT, not the full graph
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr,
+                                       src[keep], dst[keep])
+    model = S.model_from_params(params).to(DEV)
+    S.USE_FUSED_ENGINE = True
+    data = S.Batch(pos.to(DEV), types.to(DEV), ptr.to(DEV), max_beads_per_mol=40)
+    data.neighbor_list = {model.name: {"tag": model.name, "order": 2, "self_interaction": False, "rcut": 5.0,
+                                       "index_mapping": torch.stack([src[keep], dst[keep]]).to(DEV),
+                                       "cell_shifts": torch.zeros(int(keep.sum()), 3, device=DEV)}}
+    out = S.GradientsOut(model).eval()(data).out["SchNet"]
+    re, rf = _relerr(out["energy"].detach(), out["forces"].detach(), e_o.numpy(), f_o.numpy())
+    assert re < 2e-5 and rf < 2e-5
+    model.max_num_neighbors = 8
+    with pytest.raises(NotImplementedError):
+        S.GradientsOut(model).eval()(S.Batch(pos.to(DEV), types.to(DEV), ptr.to(DEV), max_beads_per_mol=40))
 
 
 @pytest.mark.parametrize("bond", [3.8, 1.6])
@@ -507,22 +532,3 @@ def test_fused_engine_empty_molecule_in_batch(params):
     assert int(eng.status[0]) == 0
     assert float(e3[1]) == 0.0
     assert torch.equal(e3[[0, 2]], e2) and torch.equal(f3, f2)
-
-
-@pytest.mark.parametrize("knob", ["FMD_NODE_RES", "FMD_EDGE_BWD_SHARE", "FMD_EDGE_FWD_SHARE"])
-def test_fused_engine_alternative_kernels(params, knob, monkeypatch):
-    """The kernel variants the experiment knobs select (streamed node kernels, per-wave Gaussians in the pair
-    kernels) stay correct: same results as the default kernels up to summation order, parity with the fp64 oracle."""
-    import flashmd_amd.schnet as S
-    from flashmd_amd import engine
-
-    pos, types, ptr = so.synth_batch(6, 120, 5.0)
-    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
-    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
-    e_d, f_d = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
-    monkeypatch.setenv(knob, "0")
-    e_a, f_a = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV))
-    monkeypatch.delenv(knob)
-    assert float((f_a - f_d).norm() / f_d.norm()) < 1e-5
-    re, rf = _relerr(e_a, f_a, e_o.numpy(), f_o.numpy())
-    assert re < 1e-4 and rf < 1e-4

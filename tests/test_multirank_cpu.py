@@ -1,6 +1,7 @@
-"""CPU, world_size 2 over gloo: the N > 1 paths -- replica sharding (no collective in the force
-path) and the parallel-tempering exchange (point-to-point send/recv) -- with every MLCG_USE_* gate off
-so the PyTorch path supplies the forces."""
+"""CPU, world_size 2 and 4 over gloo: the N > 1 paths -- replica sharding (no collective in the force
+path) and the parallel-tempering exchange (point-to-point send/recv; even phase, odd phase with idle end
+ranks, the reference-shaped acceptance matrix) -- with every MLCG_USE_* gate off so the PyTorch path supplies
+the forces."""
 import os
 import socket
 import subprocess
@@ -80,8 +81,56 @@ elif mode == "pt":
     # one write per rank: the two ranks share a pipe and print() of several arguments can interleave
     sys.stdout.write(f"PT_OK {int(ok)} {int(acc.sum())} {int(a_[0])} {int(t_[0])}\n")
     sys.stdout.flush()
-    ex(sim)                        # attempt 1: odd pairs -> nobody has a partner with 2 ranks
-    assert ex.partner(False) is None
+    # two temperatures: there is no odd pair and the reference proposes (0, 1) again (parallel_tempering.py:262-263)
+    assert ex.partner(False) == peer
+elif mode == "pt4":
+    # four temperatures, one per rank: attempt 0 pairs (0,1),(2,3); attempt 1 pairs (1,2) while ranks 0 and 3 sit out
+    # (reference parallel_tempering.py:256-284,349-366); attempt 2 is even again.  Every attempt is checked against
+    # the expectation computed from the gathered pre-exchange state, and the acceptance matrix against the
+    # reference's bookkeeping (:99-104,407-412): accepted above the diagonal, rejected below.
+    betas = [1.67, 1.42, 1.16, 0.95]
+    n_indep = 3
+    sl = slice(0, n_indep * A)
+    ptr_l = torch.arange(n_indep + 1) * A
+    ff = force_fn_for(types[sl], ptr_l)
+    sim = simulate.LangevinSimulation(ff, pos[sl] + 0.03 * rank, masses[sl], torch.full((n_indep,), betas[rank]), A, seed=11 + rank)
+    ex = simulate.DistributedReplicaExchange(betas, n_indep, A, seed=5)
+    expected = torch.zeros(world, world, dtype=torch.int64)
+    ok, evals = True, 0
+    counted = [0]
+    inner = sim.force_fn
+    def counting(x):
+        counted[0] += 1
+        return inner(x)
+    sim.force_fn = counting
+    for attempt in range(3):
+        for _ in range(2): sim.timestep()
+        x0, v0, u0 = sim.x.clone(), sim.v.clone(), sim.energy.clone()
+        allx = [torch.empty_like(x0) for _ in range(world)]; dist.all_gather(allx, x0)
+        allv = [torch.empty_like(v0) for _ in range(world)]; dist.all_gather(allv, v0)
+        allu = [torch.empty_like(u0) for _ in range(world)]; dist.all_gather(allu, u0)
+        before = counted[0]
+        ex(sim)
+        pairs = simulate.pt_pairs(world, attempt %% 2 == 0)
+        assert pairs == ([(0, 1), (2, 3)] if attempt %% 2 == 0 else [(1, 2)])
+        x_exp, v_exp, moved = allx[rank], allv[rank], False
+        for a, b in pairs:
+            g = torch.Generator().manual_seed((5 * 1000003 + attempt) * 4099 + a)
+            acc = so.pt_exchange_decisions(allu[a], allu[b], betas[a], betas[b], torch.rand(n_indep, generator=g))
+            expected[a, b] += int(acc.sum()); expected[b, a] += n_indep - int(acc.sum())
+            if rank in (a, b):
+                peer = b if rank == a else a
+                mask = acc.repeat_interleave(A)[:, None]
+                x_exp = torch.where(mask, allx[peer], allx[rank])
+                v_exp = torch.where(mask, allv[peer] * math.sqrt(betas[rank] / betas[peer]), allv[rank])
+                moved = bool(acc.any())
+        ok = ok and torch.equal(sim.x, x_exp) and torch.allclose(sim.v, v_exp)
+        # forces are re-evaluated only where something was accepted (idle ranks and all-rejected pairs: not)
+        ok = ok and (counted[0] - before == (1 if moved else 0))
+    m = ex.acceptance_matrix()
+    ok = ok and torch.equal(m, expected) and int(m.sum()) == n_indep * (2 + 1 + 2)
+    sys.stdout.write(f"PT4_OK {int(ok)} {rank} {int(m[0, 1] + m[1, 0])} {int(m[1, 2] + m[2, 1])}\n")
+    sys.stdout.flush()
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -93,11 +142,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(mode):
+def _run(mode, nproc=2):
     env = dict(os.environ, MLCG_USE_TRITON_MESSAGE_PASSING="0", MLCG_USE_FUSED_RBF="0",
                MLCG_USE_FUSED_TANH_LINEAR="0", MLCG_USE_CSR="0", MLCG_USE_SRC_CSR_GRAD_X="0",
                OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "-c",
            _WORKER % {"root": ROOT, "mode": mode}]
     # torch.distributed.run has no -c: write the worker to a temp file instead
@@ -131,3 +180,14 @@ def test_parallel_tempering_exchange_two_ranks():
     for rec in recs:
         ok, n_acc, acc0, att0 = (int(v) for v in rec)
         assert ok == 1 and acc0 == n_acc and att0 == 2
+
+
+def test_parallel_tempering_exchange_four_ranks_odd_phase_and_matrix():
+    out = _run("pt4", nproc=4)
+    import re
+
+    recs = re.findall(r"PT4_OK (\d+) (\d+) (\d+) (\d+)", out)
+    assert len(recs) == 4, out[-800:]
+    for ok, rank, n01, n12 in recs:
+        assert int(ok) == 1, f"rank {rank}"
+        assert int(n01) == 6 and int(n12) == 3   # (0,1): two even attempts x 3 replicas; (1,2): one odd attempt

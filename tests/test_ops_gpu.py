@@ -224,8 +224,10 @@ def test_w16a16_gemms(K, m, k, n):
     assert rel(K.matmul_fp32_fp16_to_fp16_v2(a.to(DEV), W).float().cpu(), _h(a).double() @ w.double()) < 1e-3
     go, yy = torch.randn(m, k, generator=g).half(), (torch.rand(m, k, generator=g) * 2 - 1).half()
     gz = _h(go.float() * (1 - yy.float() ** 2))
-    # g*(1-y^2) is formed in fp32 then rounded to fp16: an fma contraction can flip a rounding boundary
-    assert rel(K.fused_tanh_backward_grad_x_v2(go.to(DEV), yy.to(DEV), W).cpu(), gz.double() @ w.double()) < 1e-4
+    # g*(1-y^2) is formed by separately rounded fp32 operations, then rounded to fp16, as the reference's K6 does
+    # (pinned by its interpreter-executed vector, tests/test_reference_kernel_vectors_gpu.py): the dot's inputs are
+    # then identical fp16 values and only the fp32 accumulation order is left
+    assert rel(K.fused_tanh_backward_grad_x_v2(go.to(DEV), yy.to(DEV), W).cpu(), gz.double() @ w.double()) < 2e-6
 
 
 # ---------------------------------------------------------------------------------------- N1, (e)
