@@ -23,6 +23,30 @@
 
 #include "fmd_common.h"
 
+// Diagnostic build only (`make stamps` -> build_stamps/libflashmd_hip_stamps.so, never loaded by the package): every
+// wave accumulates the cycles it spends in each phase of the pair kernels' tile loop; tools/phase_stamps.py reads them.
+#ifdef FMD_PHASE_STAMPS
+#define FMD_NSTAMP 12
+#define FMD_STAMP_DECL unsigned long long ts_[FMD_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = 0;
+#define FMD_STAMP_START tprev_ = __builtin_readcyclecounter();
+#define FMD_MARK(k)                                                  \
+  {                                                                  \
+    const unsigned long long now_ = __builtin_readcyclecounter();    \
+    ts_[k] += now_ - tprev_;                                         \
+    tprev_ = now_;                                                   \
+  }
+#define FMD_STAMP_FLUSH(args_, wave_)                                                                        \
+  if ((args_).stamps && (threadIdx.x & 63) == 0) {                                                           \
+    unsigned long long* o_ = (args_).stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (wave_)) * FMD_NSTAMP; \
+    for (int k_ = 0; k_ < FMD_NSTAMP; ++k_) o_[k_] = ts_[k_];                                                \
+  }
+#else
+#define FMD_STAMP_DECL
+#define FMD_STAMP_START
+#define FMD_MARK(k)
+#define FMD_STAMP_FLUSH(args_, wave_)
+#endif
+
 namespace fmd_eng {
 
 constexpr int F = 128;            // hidden = filters
@@ -59,6 +83,9 @@ struct EdgeArgs {
   float gamma, rc;
   int cap, n_split;
   int max_beads;           // the caller's bound on beads per molecule: what the dynamic LDS was sized for
+#ifdef FMD_PHASE_STAMPS
+  unsigned long long* stamps;  // diagnostic build (make stamps) only: [workgroup][8 waves][FMD_NSTAMP] cycle totals
+#endif
 };
 
 
@@ -180,9 +207,24 @@ constexpr int TILE_H_BYTES = 32 * LDH * 2;     // one fp16 tile
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
 typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
 
-// ---- packed-fp32 forms (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 process two values per VALU slot):
-// the producers of the split pair kernels are VALU-issue bound, so their arithmetic is written on pairs.
+// ---- arithmetic on pairs of values.  Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) halves the
+// instruction count, but such an instruction cannot issue while the OTHER wave of the SIMD has an MFMA in flight
+// (tools/ubench/coissue.hip: a v_pk_mul_f32 stream beside an MFMA stream takes the SUM of both times, older or
+// younger; plain v_fma_f32 / v_cvt_pkrtz / v_fma_mix / transcendentals overlap within ~15 %).  In the pair kernels
+// the two waves of a SIMD are one producer and one consumer whose VALU phases are meant to run under each other's
+// MFMA bursts, so they use the scalar pair type (FMD_SCALAR_PAIRS, set by their translation units, which are also
+// compiled with -fno-slp-vectorize); the node kernels run one wave per SIMD and keep the packed form.
+#ifdef FMD_SCALAR_PAIRS
+struct f32x2 {
+  float x, y;
+  __device__ __forceinline__ float operator[](int i) const { return i ? y : x; }
+};
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+#else
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#endif
 constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 exp2_2(f32x2 x) {
@@ -191,6 +233,12 @@ __device__ __forceinline__ f32x2 exp2_2(f32x2 x) {
 // tanh = 1 - 2 rcp(e^{2x} + 1) on a pair (see fmd_tanh_fast)
 __device__ __forceinline__ f32x2 tanh_fast2(f32x2 x) {
   const f32x2 e = exp2_2(x * splat2(2.0f * LOG2E)) + splat2(1.0f);
+  const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  return splat2(1.0f) - splat2(2.0f) * rc;
+}
+// the same for an argument already multiplied by 2 log2(e) (the pair kernels fold that factor into C and the bias)
+__device__ __forceinline__ f32x2 tanh_from_scaled2(f32x2 y) {
+  const f32x2 e = exp2_2(y) + splat2(1.0f);
   const f32x2 rc = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
   return splat2(1.0f) - splat2(2.0f) * rc;
 }
@@ -205,7 +253,11 @@ __device__ __forceinline__ f32x2 comb2(const f32x16& a1, const f32x16& a2, int r
   return f32x2{a1[r], a1[r + 1]} + f32x2{a2[r], a2[r + 1]} * f32x2{1.0f / 2048.0f, 1.0f / 2048.0f};
 }
 __device__ __forceinline__ uint32_t half_pair(f32x2 x) {  // v_cvt_pk_f16_f32 (RTE)
+#ifdef FMD_SCALAR_PAIRS
+  const f16x2 h = {(_Float16)x.x, (_Float16)x.y};
+#else
   const f16x2 h = __builtin_convertvector(x, f16x2);
+#endif
   uint32_t u;
   __builtin_memcpy(&u, &h, 4);
   return u;
@@ -216,6 +268,17 @@ __device__ __forceinline__ void split_pair(f32x2 x, uint32_t& hi, uint32_t& lo) 
   const f32x2 xs = x * splat2(SPLIT_SCALE);  // (x - h) 2048 as x 2048 - h 2048: v_fma_mix reads the half directly
   const hv2 l = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)h[0], -SPLIT_SCALE, xs[0]),
                                            __builtin_fmaf((float)h[1], -SPLIT_SCALE, xs[1]));
+  __builtin_memcpy(&hi, &h, 4);
+  __builtin_memcpy(&lo, &l, 4);
+}
+// The same with an UNSCALED low word, lo = f16(x - hi): hi + lo then carries x to ~2^-24 absolute for |x| <~ 2 (fp16
+// denormals are honoured by the conversions and by the MFMA: tools/ubench/denorm_mfma.hip), which is fp32 grade for
+// operands of bounded magnitude -- weights, Gaussians, C tanh -- and lets all three products of a split contraction
+// share ONE accumulator (no 1/2048 recombination, 16 registers less per GEMM).  Unbounded operands (gW) keep the
+// scaled form above.
+__device__ __forceinline__ void split_pair_u(f32x2 x, uint32_t& hi, uint32_t& lo) {
+  const hv2 h = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+  const hv2 l = __builtin_amdgcn_cvt_pkrtz(x[0] - (float)h[0], x[1] - (float)h[1]);
   __builtin_memcpy(&hi, &h, 4);
   __builtin_memcpy(&lo, &l, 4);
 }
@@ -235,8 +298,8 @@ __device__ __forceinline__ void rbf_fragments(float d, float gl, const f32x4& c0
       xl[j] = 0;
       if (WITH_DIFF) { qh[j] = half_pair(raw * diff); ql[j] = 0; }
     } else {
-      split_pair(raw, xh[j], xl[j]);
-      if (WITH_DIFF) split_pair(raw * diff, qh[j], ql[j]);
+      split_pair_u(raw, xh[j], xl[j]);
+      if (WITH_DIFF) split_pair_u(raw * diff, qh[j], ql[j]);
     }
   }
   __builtin_memcpy(&bh, xh, 16);
@@ -255,6 +318,16 @@ __device__ __forceinline__ void mfma_prod(const f16x8& ah, const f16x8& al, cons
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
   }
+}
+// one accumulator, operands with unscaled low words (split_pair_u / pack scale 1): acc += a_hi b_hi + a_hi b_lo + a_lo b_hi
+template <bool HALF>
+__device__ __forceinline__ void mfma_merged(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                            f32x16& acc) {
+  if (!HALF) {  // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
 }
 // acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
 __device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,

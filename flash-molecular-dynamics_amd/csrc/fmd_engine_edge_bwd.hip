@@ -2,6 +2,7 @@
 // respect to x1 (-> gx1 aggregate) and to the pair distance (-> dE/dd, including the d/dd of the cutoff that the
 // reference's Triton path drops).  Replaces K6/K7 + K10/K2 (kernels/cfconv_kernels.py:973-1035,
 // 1174-1208,178-258; csr_kernels.py:302-396) and the autograd chain through them on the whole-path route.
+#define FMD_SCALAR_PAIRS 1
 #include "fmd_engine.h"
 
 namespace {
@@ -18,6 +19,30 @@ struct SegRegsB {             // consumer state of one tile (register r = 4q + e
   uint32_t oi[4], oj[16];
   float xi[4], xj[16], gi[4], gj[16];
 };
+
+// gW hand-over.  The consumers hold gW with the feature on the lane and the tile's pairs in registers; the u GEMM
+// contracts over features, i.e. over the lane index of that layout, so the tile crosses LDS transposed
+// (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's operand"): image [feature][pair], 64-byte
+// rows of 32 halves, hi plane then lo plane (GW_PLANE bytes each) in the region of the hidden tiles.  A consumer lane
+// stores its registers 4q .. 4q+3 (pairs 8q + 4h .. + 3 of its feature) as one 8-byte word, the producers read B
+// fragments back with ds_read_b64_tr_b16.  The 8-byte units of a row are XOR-swizzled with (row >> 1) & 7 so that the
+// 16 lanes of a store group (consecutive features, same unit) hit different banks; rows 4 apart keep the transposed
+// reads conflict free as they are.
+constexpr int GW_PLANE = 128 * 64;
+__device__ __forceinline__ int gw_row_off(int feature, int unit) {
+  return feature * 64 + 8 * (unit ^ ((feature >> 1) & 7));
+}
+typedef __fp16 fmd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8 gw_frag(const char* a1, const char* a2) {
+  const fmd_h4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fmd_h4*)(uintptr_t)(uint32_t)(uintptr_t)a1);
+  const fmd_h4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fmd_h4*)(uintptr_t)(uint32_t)(uintptr_t)a2);
+  f16x8 r;
+  __builtin_memcpy(&r, &v0, 8);
+  __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &v1, 8);
+  return r;
+}
 
 // FS: feature-split mode for molecules of 284..566 beads, see edge_fwd_split_kernel (each of the molecule's two
 // workgroups: all tiles, 64 features of gx1, its own dE/dd slab -- the u GEMM only sees its 64 features of gW).
@@ -47,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   if (NEED_GX1)
     for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 64) cen_l[tid] = a.centers[tid];
-  if (tid < 128) b0_l[tid] = a.b0[tid];
+  if (tid < 128) b0_l[tid] = a.b0[tid] * (2.0f * LOG2E);  // pre-multiplied: tanh(z) = 1 - 2 / (exp2(2 log2(e) z) + 1)
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
@@ -58,7 +83,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
   const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
+  FMD_STAMP_DECL
   __syncthreads();
+  FMD_STAMP_START
   if (T0 < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
@@ -79,6 +106,12 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + ku0 + s) * 64 + lane];
         if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + ku0 + s) * 64 + lane];
       }
+      // gW hand-over image (see gw_row_off): this lane's two read addresses of k-step 0 in the 16-lane group scheme of
+      // ds_read_b64_tr_b16 -- lane 4q+p of a group addresses row (feature) f0 + q, pairs 16 g + 4p .. + 3
+      const int tg = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+      const char* gw_img = reinterpret_cast<const char*>(hid_hi);
+      const char* gw_a1 = gw_img + gw_row_off(16 * ku0 + 8 * h + tq, 4 * tg + tp);
+      const char* gw_a2 = gw_img + gw_row_off(16 * ku0 + 8 * h + 4 + tq, 4 * tg + tp);
       // meta of the tile to stage next (lane = pair view)
       float d_n, c_n, dc_n, gd_n = 0.f;
       auto fetch = [&](int t) {
@@ -98,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         const float d = d_n, C = c_n, dC = dc_n;
         gd_nx = gd_n;
         fetch(t_fetch);
-        f32x16 z1 = zero16(), z2 = zero16(), p1 = zero16(), p2 = zero16();
+        f32x16 z1 = zero16(), p1 = zero16();
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
           f32x4 c0, c1;
@@ -117,17 +150,20 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
             } else {
-              mfma_split(a0h[s], a0l[s], bh, bl, z1, z2);
-              mfma_split(ach[s], acl[s], bh, bl, p1, p2);
+              mfma_merged<false>(a0h[s], a0l[s], bh, bl, z1);
+              mfma_merged<false>(ach[s], acl[s], bh, bl, p1);
             }
           } else {
             rbf_fragments<true, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
-            mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, z1, z2);
-            mfma_prod<HALF>(a0h[s], a0l[s], ph, pl, p1, p2);
+            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, z1);
+            mfma_merged<HALF>(a0h[s], a0l[s], ph, pl, p1);
           }
           __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
         }
-        const float g2c = 2.0f * a.gamma * C, dm = d - a.c0;
+        // z' = dz/dd = 2 gamma C G1 + C' G0; in the shared-Gaussian form G1 = (d - c0) G0 - Gc, so
+        // z' = (2 gamma C (d - c0) + C') G0 - 2 gamma C Gc
+        const float g2c = 2.0f * a.gamma * C, C2 = C * (2.0f * LOG2E);
+        const float za = (SHARE && !HALF) ? g2c * (d - a.c0) + dC : dC;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_l + 32 * w + 8 * q + 4 * h);
@@ -135,15 +171,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int ep = 0; ep < 2; ++ep) {
             const int r = 4 * q + 2 * ep;
-            const f32x2 g0 = comb2<HALF>(z1, z2, r);
-            f32x2 g1 = comb2<HALF>(p1, p2, r);
-            if (SHARE && !HALF) g1 = splat2(dm) * g0 - g1;
-            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
+            const f32x2 g0 = f32x2{z1[r], z1[r + 1]};
+            f32x2 g1 = f32x2{p1[r], p1[r + 1]};
+            const f32x2 zp = (SHARE && !HALF) ? splat2(za) * g0 - splat2(g2c) * g1
+                                              : splat2(g2c) * g1 + splat2(za) * g0;
+            const f32x2 hv = tanh_from_scaled2(splat2(C2) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
             // the tile carries C h: L1 then yields W = filt C
-            if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
-            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
-            const f32x2 kk = splat2(C) * ((splat2(1.0f) - hv * hv) * (splat2(g2c) * g1 + splat2(dC) * g0)) +
-                             splat2(dC) * hv;
+            const f32x2 ch = splat2(C) * hv;
+            if (HALF) { th[ep] = half_pair(ch); tl[ep] = 0; }
+            else split_pair_u(ch, th[ep], tl[ep]);
+            // k = d(C h)/dd = C (1 - h^2) z' + C' h = (C - (C h) h) z' + C' h
+            const f32x2 kk = (splat2(C) - ch * hv) * zp + splat2(dC) * hv;
             k_nx[r] = kk[0];
             k_nx[r + 1] = kk[1];
           }
@@ -176,23 +214,27 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       rotate();
       put();
       __syncthreads();  // A(first)
+      FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
         compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+        FMD_MARK(0)
         __syncthreads();     // B(t)
+        FMD_MARK(1)
         __syncthreads();     // C(t): gW(t) visible
+        FMD_MARK(2)
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
         f32x16 u1 = zero16(), u2 = zero16();
         {
-          // gW fragments read one k-step ahead (fenced: see the consumers' L1 loop)
-          const _Float16* gph = hid_hi + c32 * LDH + 8 * h + 16 * ku0;
-          const _Float16* gpl = hid_lo + c32 * LDH + 8 * h + 16 * ku0;
-          f16x8 bh = *reinterpret_cast<const f16x8*>(gph), bl = *reinterpret_cast<const f16x8*>(gpl);
+          // gW fragments: two transposed reads (features 8h + 0..3 and 8h + 4..7 of the k-step) per plane, one
+          // k-step ahead of their MFMAs (fenced: see the consumers' L1 loop)
+          f16x8 bh = gw_frag(gw_a1, gw_a2), bl = bh;
+          if (!HALF) bl = gw_frag(gw_a1 + GW_PLANE, gw_a2 + GW_PLANE);
           static_for<0, NKU>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             f16x8 nh = bh, nl = bl;
             if constexpr (s + 1 < NKU) {
-              nh = *reinterpret_cast<const f16x8*>(gph + 16 * (s + 1));
-              nl = *reinterpret_cast<const f16x8*>(gpl + 16 * (s + 1));
+              nh = gw_frag(gw_a1 + 1024 * (s + 1), gw_a2 + 1024 * (s + 1));
+              if (!HALF) nl = gw_frag(gw_a1 + GW_PLANE + 1024 * (s + 1), gw_a2 + GW_PLANE + 1024 * (s + 1));
             }
             mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
             bh = nh; bl = nl;
@@ -209,14 +251,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
         tot = fmd_xor32_sum(tot);
         if (h == 0) red[w * 32 + c32] = tot;
+        FMD_MARK(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
+        FMD_MARK(4)
         if (w == 0 && h == 0) {
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
           pgd[t * 32 + c32] = FIRST ? sum : gd_cu + sum;
         }
         put();               // hidden tiles of t+S
         rotate();
+        FMD_MARK(5)
         __syncthreads();     // A(t+S)
+        FMD_MARK(6)
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
@@ -240,7 +286,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       float d_m = 0.f;  // SHARE: distance of pair c32 of the fetched tile
       auto fetch_meta = [&](int t) {
         const int base = min(t * 32, last_base);
-        if (SHARE) d_m = pdist[base + c32];
         static_for<0, 4>([&](auto qc) {
           constexpr int q = decltype(qc)::value;
           const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
@@ -282,9 +327,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
         }
       };
+      // Schedule of one tile (consumer side), between A and B: gW from the rows gathered one tile ago, L1, then the
+      // aggregate update interleaved with the gathers of the next tile's rows (they need ~2-3 thousand cycles to
+      // arrive under load: issued here they land while the producers run the u GEMM and stage the next tile).
+      auto fetch_d = [&](int t) {
+        if (SHARE) d_m = pdist[min(t * 32, last_base) + c32];
+      };
+      fetch_d(T0);
       fetch_meta(T0);
       fill();
       if (SHARE) share_fragments();
+      fetch_d(T0 + S);
       fetch_meta(T0 + S);
       if (SHARE) {
         __syncthreads();  // first tile's fragments visible
@@ -292,9 +345,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         share_fragments();
       }
       __syncthreads();  // A(first)
+      FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
+        fetch_d(t + 2 * S);  // for the fragments written after C(t)
         if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
-          fetch_meta(t + 2 * S);
           __syncthreads();  // B(t)
           __syncthreads();  // C(t)
           if (SHARE) share_fragments();
@@ -302,30 +356,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           __syncthreads();  // A(t+S)
           continue;
         }
-        // L1 recomputed: filt slice (lane = feature, registers = pairs)
-        f32x16 acc1 = zero16(), acc2 = zero16();
-        {
-          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
-          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
-          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
-          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
-          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
-          static_for<0, 8>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            f16x8 ahn = ah1, aln = al1;
-            if constexpr (s + 2 < 8) {
-              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
-              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
-            }
-            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
-            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-        f32x16 fl;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) fl[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
         // gW = x1[i] g[j] + x1[j] g[i], split two values at a time: gwh[p] = hi halves of entries 2p, 2p+1,
         // gwl[p] = their lo halves
         f16x2 gwh[8], gwl[8];
@@ -340,45 +370,118 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           __builtin_memcpy(&gwh[p2], &hw, 4);
           __builtin_memcpy(&gwl[p2], &lw, 4);
         }
-        asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete before the barrier
-        // The aggregate update and the refill of X need nothing from the producers: they run here,
-        // while the producers are still staging the next tile, not between the later barriers.
-        if (NEED_GX1) {   // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j)
-          static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            float Wq[4], vj[4];
+#pragma unroll
+        for (int p2 = 0; p2 < 8; ++p2) asm volatile("" : "+v"(gwh[p2]), "+v"(gwl[p2]));  // ahead of the MFMAs
+        FMD_MARK(0)
+        // L1 recomputed: filt slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16();
+        {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            mfma_merged<HALF>(ah0, al0, b1h[s], b1l[s], acc1);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        f32x16 fl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fl[r] = acc1[r];
+        asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete
+        FMD_MARK(1)
+        // gx1[i] += sum_j g[j] W, gx1[j] += g[i] W  (segment: one centre, distinct j), interleaved with the refill of
+        // X for tile t+S: a segment's aggregate rows are read, the previous segment's gathers are issued while those
+        // reads are in flight (a gather costs the CU's address unit ~16 cycles, an LDS round trip ~100), then the
+        // segment is finished and its registers -- free from here on -- take the next tile's offsets.
+        float vj[4], cval = 0.f;
+        auto seg_reads = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          if (NEED_GX1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vj[e] = *reinterpret_cast<const float*>(gx1b + lo(X.oj[4 * q + e]));
+            cval = *reinterpret_cast<const float*>(gx1b + lo(X.oi[q]));
+          }
+        };
+        auto seg_finish = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          if (NEED_GX1) {
             float si = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              Wq[e] = fl[4 * q + e];  // already filt * C
-              vj[e] = *reinterpret_cast<const float*>(gx1b + lo(X.oj[4 * q + e]));
-              si += X.gj[4 * q + e] * Wq[e];
+              const float Wqe = fl[4 * q + e];  // already filt * C
+              si += X.gj[4 * q + e] * Wqe;
+              *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wqe;
             }
-            const float cval = *reinterpret_cast<const float*>(gx1b + lo(X.oi[q]));
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wq[e];
             si = fmd_segment_sum(si, X.oi[q]);
             *reinterpret_cast<float*>(gx1b + lo(X.oi[q])) = cval + si;
-          });
-        }
-        fill();           // X <- tile t+S
-        fetch_meta(t + 2 * S);
-        __syncthreads();  // B(t): hidden tiles consumed
+          }
+        };
+        auto seg_refill = [&](auto qc) {  // segment q of X <- tile t+S (offsets fetched one tile ago)
+          constexpr int q = decltype(qc)::value;
+          X.oi[q] = oi_m[q] + col4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {  // ds_write_b16 of each half
-          hid_hi[tile_row(r, h) * LDH + col] = gwh[r >> 1][r & 1];
-          if (!HALF) hid_lo[tile_row(r, h) * LDH + col] = gwl[r >> 1][r & 1];
+          for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+          X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+          X.gi[q] = *reinterpret_cast<const float*>(gab + X.oi[q]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
+            X.gj[4 * q + e] = *reinterpret_cast<const float*>(gab + X.oj[4 * q + e]);
+          }
+        };
+        seg_reads(std::integral_constant<int, 0>{});
+        static_for<0, 4>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          seg_finish(qc);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (q + 1 < 4) seg_reads(std::integral_constant<int, q + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          seg_refill(qc);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        FMD_MARK(5)
+        fetch_meta(t + 2 * S);
+        FMD_MARK(6)
+        __syncthreads();  // B(t): hidden tiles consumed
+        FMD_MARK(2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // pairs 8q + 4h .. + 3 of this lane's feature: one 8-byte store per plane
+          char* dst = reinterpret_cast<char*>(hid_hi) + gw_row_off(col, 2 * q + h);
+          uint32_t w0, w1;
+          __builtin_memcpy(&w0, &gwh[2 * q], 4);
+          __builtin_memcpy(&w1, &gwh[2 * q + 1], 4);
+          *reinterpret_cast<uint2*>(dst) = uint2{w0, w1};
+          if (!HALF) {
+            __builtin_memcpy(&w0, &gwl[2 * q], 4);
+            __builtin_memcpy(&w1, &gwl[2 * q + 1], 4);
+            *reinterpret_cast<uint2*>(dst + GW_PLANE) = uint2{w0, w1};
+          }
         }
+        FMD_MARK(3)
         __syncthreads();  // C(t): gW visible
+        FMD_MARK(4)
         // the producers read fragments only while staging (between A and B): the tile they stage in the
-        // next iteration, t + 2S, is written here, in the consumers' idle window
+        // next iteration, t + 2S, is written here
         if (SHARE) share_fragments();
+        FMD_MARK(7)
         __syncthreads();  // D(t)
+        FMD_MARK(8)
         __syncthreads();  // A(t+S)
+        FMD_MARK(9)
       }
     }
   }
+  FMD_STAMP_FLUSH(a, wave)
   if (NEED_GX1) {
     __syncthreads();
     float* out = a.slabs + split * a.slab_stride + a0 * F;

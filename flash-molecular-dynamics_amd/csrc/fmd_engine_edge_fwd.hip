@@ -2,6 +2,7 @@
 // CFConv message passing (schnet.py:706-715) of one interaction block over the undirected pair list; the molecule's
 // aggregate stays in LDS.  Replaces K3/K4/K5 + K9 of the reference (kernels/cfconv_kernels.py:469-540,657-720,
 // 780-832; csr_kernels.py:625-724) on the whole-path route.
+#define FMD_SCALAR_PAIRS 1
 #include "fmd_engine.h"
 
 namespace {
@@ -55,7 +56,9 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
   const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
+  FMD_STAMP_DECL
   __syncthreads();
+  FMD_STAMP_START
   if (T0 < ntiles) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
@@ -72,15 +75,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q)  // bias pre-multiplied by 2 log2(e): tanh(z) = 1 - 2 / (exp2(2 log2(e) z) + 1)
+        b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h) * (2.0f * LOG2E);
       float d_n = pdist[min(T0 * 32, last_base) + c32], c_n = pcut[min(T0 * 32, last_base) + c32];
       f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
       auto compute = [&](int t_next) {
-        const float d = d_n, C = c_n;
+        const float d = d_n, C = c_n, C2 = c_n * (2.0f * LOG2E);
         const int nb = min(t_next * 32, last_base);
         d_n = pdist[nb + c32];
         c_n = pcut[nb + c32];
-        f32x16 acc1 = zero16(), acc2 = zero16();
+        f32x16 acc1 = zero16();
 #pragma unroll
         for (int s = 0; s < NS0; ++s) {
           f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           } else {
             rbf_fragments<false, HALF>(d, gl, cen[SH ? 0 : 2 * s], cen[SH ? 0 : 2 * s + 1], bh, bl, ph, pl);
           }
-          mfma_prod<HALF>(a0h[s], a0l[s], bh, bl, acc1, acc2);
+          mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -100,10 +104,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           for (int ep = 0; ep < 2; ++ep) {
             const int r = 4 * q + 2 * ep;
             // z = C (W0 raw) + b0 ; the tile carries C tanh(z): the consumers' L1 then yields W = filt C
-            const f32x2 g0 = comb2<HALF>(acc1, acc2, r);
-            const f32x2 hv = tanh_fast2(splat2(C) * g0 + f32x2{b0r[q][2 * ep], b0r[q][2 * ep + 1]});
+            const f32x2 g0 = f32x2{acc1[r], acc1[r + 1]};
+            const f32x2 hv = tanh_from_scaled2(splat2(C2) * g0 + f32x2{b0r[q][2 * ep], b0r[q][2 * ep + 1]});
             if (HALF) { th[ep] = half_pair(splat2(C) * hv); tl[ep] = 0; }
-            else split_pair(splat2(C) * hv, th[ep], tl[ep]);
+            else split_pair_u(splat2(C) * hv, th[ep], tl[ep]);
           }
           __builtin_memcpy(&hh[q], th, 8);
           __builtin_memcpy(&hl[q], tl, 8);
@@ -124,11 +128,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       if (SH) __syncthreads();  // ... and consumed: the consumers write the second tile's
       put();
       __syncthreads();  // A(first)
+      FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
         compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        FMD_MARK(0)
         __syncthreads();     // B(t)
+        FMD_MARK(1)
         put();
+        FMD_MARK(2)
         __syncthreads();     // A(t+S)
+        FMD_MARK(3)
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
@@ -237,9 +246,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
       f32x16 fl_prev = zero16();
       __syncthreads();  // A(first)
+      FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
-        f32x16 acc1 = zero16(), acc2 = zero16();
+        f32x16 acc1 = zero16();
         {
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
@@ -254,28 +264,78 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
               aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
-            mfma_prod<HALF>(ah0, al0, b1h[s], b1l[s], acc1, acc2);
+            mfma_merged<HALF>(ah0, al0, b1h[s], b1l[s], acc1);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });
         }
-        message(fl_prev);  // tile t-S (X holds its gathers)
-        fill();            // X <- tile t (meta fetched one tile ago; lands before the next update)
+        FMD_MARK(0)
+        // aggregate update of tile t-S (X holds its gathers) interleaved with the refill of X for tile t, segment by
+        // segment: the next segment's aggregate rows are requested, then the finished segment's registers take the new
+        // offsets and its gathers are issued while that LDS read is in flight (a gather costs the CU's address unit
+        // ~16 cycles, an LDS round trip ~100), then the next segment is finished, ...
+        {
+          float vj[4], cval;
+          auto seg_reads = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vj[e] = *reinterpret_cast<const float*>(aggb + lo(X.oj[4 * q + e]));
+            cval = *reinterpret_cast<const float*>(aggb + lo(X.oi[q]));
+          };
+          auto seg_finish = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float si = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float Wqe = fl_prev[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
+              si += X.xj[4 * q + e] * Wqe;
+              *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wqe;
+            }
+            si = fmd_segment_sum(si, X.oi[q]);
+            // both halves store the same value to the same address
+            *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
+          };
+          auto seg_refill = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            X.oi[q] = oi_m[q] + col4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+            X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
+          };
+          seg_reads(std::integral_constant<int, 0>{});
+          static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            seg_finish(qc);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q + 1 < 4) seg_reads(std::integral_constant<int, q + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            seg_refill(qc);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        FMD_MARK(1)
         fetch_meta(t + S);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fl_prev[r] = HALF ? acc1[r] : acc1[r] + acc2[r] * SPLIT_INV;
+        for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r];
         asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
+        FMD_MARK(2)
         __syncthreads();  // B(t): hidden tiles consumed
+        FMD_MARK(3)
         if (SH) {  // the producers only write the hidden tile now: the fragments they stage from next are replaced
           share_fragments();
           fetch_d(t + 3 * S);
         }
+        FMD_MARK(4)
         __syncthreads();  // A(t+S)
+        FMD_MARK(5)
       }
       message(fl_prev);  // last tile
       }
     }
   }
+  FMD_STAMP_FLUSH(a, wave)
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
   if (FS) {  // this half's 64 features, zeros in the other half (the node kernels add the slabs)

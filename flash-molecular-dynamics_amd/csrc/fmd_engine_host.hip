@@ -58,13 +58,15 @@ BlockOff block_off(const PackLayout& L, int l) {
   return o;
 }
 
-// fp16 hi/lo split of an operand for v_mfma_f32_32x32x16_f16: x ~ hi + lo / 2048 with hi = f16(x),
-// lo = f16((x - hi) * 2048).  M is [n_out][n_k] row-major (or its transpose when `transposed`): the operand that
+// fp16 hi/lo split of an operand for v_mfma_f32_32x32x16_f16: x ~ hi + lo / lo_scale with hi = f16(x),
+// lo = f16((x - hi) * lo_scale).  lo_scale = 2048 for operands whose partner is a scaled activation split (two
+// accumulators: node kernels, the u GEMM); lo_scale = 1 for the contractions that run on ONE accumulator (filter layers
+// 0 and 1: weights and their bounded activations both carry an unscaled low word, fmd_engine.h split_pair_u).  M is [n_out][n_k] row-major (or its transpose when `transposed`): the operand that
 // multiplies a row tile as out[row][o] = sum_k a[row][k] * M[o][k].  Record (w, s, lane) holds the 8 halves
 // M[32w + (lane&31)][16s + 8(lane>>5) + j], zero outside the matrix (the A-operand and the B-operand fragment of that
 // instruction index their matrix the same way).
 void pack_split(float* dst_hi, float* dst_lo, const float* M, int n_out, int n_k, int n_steps,
-                bool transposed) {
+                bool transposed, float lo_scale = 2048.0f) {
   _Float16* hi = reinterpret_cast<_Float16*>(dst_hi);
   _Float16* lo = reinterpret_cast<_Float16*>(dst_lo);
   for (int w = 0; w < 4; ++w)
@@ -77,7 +79,7 @@ void pack_split(float* dst_hi, float* dst_lo, const float* M, int n_out, int n_k
           const _Float16 h = (_Float16)v;
           const int64_t idx = (((int64_t)w * n_steps + s) * 64 + l) * 8 + j;
           hi[idx] = h;
-          lo[idx] = (_Float16)((v - (float)h) * 2048.0f);
+          lo[idx] = (_Float16)((v - (float)h) * lo_scale);
         }
 }
 // node-kernel operand: hi record followed by lo record (SLICE floats)
@@ -175,7 +177,21 @@ int ensure_kernel_attrs() {
   return rc;
 }
 
+#ifdef FMD_PHASE_STAMPS
+unsigned long long* g_stamps = nullptr;   // diagnostic build only
+int g_stamp_block = -1, g_stamp_fwd = 0;  // which launch writes them
+#endif
+
 }  // namespace
+
+#ifdef FMD_PHASE_STAMPS
+extern "C" int fmd_debug_set_stamps(void* device_buffer, int block, int fwd) {
+  g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
+  g_stamp_block = block;
+  g_stamp_fwd = fwd;
+  return FMD_OK;
+}
+#endif
 
 extern "C" int64_t fmd_schnet_pack_bytes(const fmd_schnet_desc* desc) {
   if (!desc_ok(desc)) return FMD_EINVAL;
@@ -219,16 +235,16 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     pack_node(out + o.l3, b.lin_w, F, F, false);
     memcpy(out + o.b3, b.lin_b, F * sizeof(float));
     pack_node(out + o.l3t, b.lin_w, F, F, true);
-    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false);
+    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false, 1.0f);
     {  // Wc[f][k] = (centre_k - cutoff/2) W0[f][k]:  W0 (raw (d - centre)) = (d - cutoff/2) W0 raw - Wc raw
       std::vector<float> wc((size_t)F * desc->num_rbf);
       const float c0 = 0.5f * desc->cutoff;
       for (int f = 0; f < F; ++f)
         for (int k = 0; k < desc->num_rbf; ++k)
           wc[(size_t)f * desc->num_rbf + k] = (centers[k] - c0) * b.f0_w[(size_t)f * desc->num_rbf + k];
-      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, 4, false);
+      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, 4, false, 1.0f);
     }
-    pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false);
+    pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false, 1.0f);
     pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
   }
   int in_w = F;
@@ -313,6 +329,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
+#ifdef FMD_PHASE_STAMPS
+    ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
+#endif
     if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, n_mol, s);
     return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, n_mol, s);
   };

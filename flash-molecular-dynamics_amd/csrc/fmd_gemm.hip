@@ -138,7 +138,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const void* __restrict__ 
           const float y = (float)reinterpret_cast<const _Float16*>(Yp)[idx];
           // the reference forms g * (1 - y*y) with separately rounded fp32 operations before the fp16
           // rounding (cfconv_kernels.py:1019-1023); an fma contraction here moves fp16 rounding boundaries
-          v = __fmul_rn(g, __fsub_rn(1.0f, __fmul_rn(y, y)));
+          {
+#pragma clang fp contract(off)
+            const float yy = y * y;
+            const float om = 1.0f - yy;
+            v = g * om;
+          }
         }
       }
       As[r * G16_LD + c] = (_Float16)v;

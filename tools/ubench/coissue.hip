@@ -12,7 +12,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define REP4(x) x x x x
 #define REP8(x) x x x x x x x x
 
-enum Role { IDLE = 0, MFMA = 1, VALU = 2, MIX = 3, LDSRW = 4, TRANS = 5, PKV = 6, MIX3 = 7 };
+enum Role { IDLE = 0, MFMA = 1, VALU = 2, MIX = 3, LDSRW = 4, TRANS = 5, PKV = 6, MIX3 = 7, CVT = 8, MIXF = 9, CVTS = 10, PKMUL = 11, PERM = 12, SWAP = 13 };
 
 // one "unit" of each role ~ 8 MFMAs (256 pipe cycles) or 64 VALU (256 issue cycles)
 template <int role>
@@ -36,6 +36,30 @@ __device__ __forceinline__ void run_role(int iters, float& a0, float& a1, float&
       REP8(asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n"
                         "v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n"
                         : "+v"(p0), "+v"(p1));)
+    } else if (role == CVT) {  // 64 v_cvt_pkrtz_f16_f32
+      REP8(asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %3, %1, %2\n v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %3, %1, %2\n"
+                        "v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %3, %1, %2\n v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %3, %1, %2\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (role == MIXF) {  // 64 v_fma_mix_f32
+      REP8(asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n"
+                        "v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (role == CVTS) {  // 32 v_cvt_f16_f32 + 32 v_cvt_f32_f16
+      REP8(asm volatile("v_cvt_f16_f32 %0, %1\n v_cvt_f32_f16 %2, %3\n v_cvt_f16_f32 %0, %1\n v_cvt_f32_f16 %2, %3\n"
+                        "v_cvt_f16_f32 %0, %1\n v_cvt_f32_f16 %2, %3\n v_cvt_f16_f32 %0, %1\n v_cvt_f32_f16 %2, %3\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (role == PKMUL) {  // 64 v_pk_mul_f32
+      REP8(asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n"
+                        "v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %0\n"
+                        : "+v"(p0), "+v"(p1));)
+    } else if (role == PERM) {  // 64 v_perm_b32
+      REP8(asm volatile("v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n"
+                        "v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n v_perm_b32 %0, %1, %2, %3\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (role == SWAP) {  // 64 v_permlane32_swap
+      REP8(asm volatile("v_permlane32_swap_b32 %0, %1\n s_nop 0\n v_permlane32_swap_b32 %2, %3\n s_nop 0\n v_permlane32_swap_b32 %0, %1\n s_nop 0\n v_permlane32_swap_b32 %2, %3\n s_nop 0\n"
+                        "v_permlane32_swap_b32 %0, %1\n s_nop 0\n v_permlane32_swap_b32 %2, %3\n s_nop 0\n v_permlane32_swap_b32 %0, %1\n s_nop 0\n v_permlane32_swap_b32 %2, %3\n s_nop 0\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
     } else if (role == MIX) {  // 8 MFMA, each followed by 5 independent VALU (program order interleave)
       REP4(acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc0, 0, 0, 0);
            asm volatile("v_fma_f32 %0, %0, %0, 1.0\n v_fma_f32 %1, %1, %1, 1.0\n v_fma_f32 %2, %2, %2, 1.0\n v_fma_f32 %3, %3, %3, 1.0\n v_fma_f32 %0, %0, %0, 1.0\n"
@@ -185,6 +209,19 @@ int main() {
   run<MFMA, TRANS>("older MFMA | younger TRANS");
   run<PKV, IDLE>("PKV alone");
   run<MFMA, PKV>("older MFMA | younger PKV");
+  run<CVT, IDLE>("CVT (cvt_pkrtz) alone");
+  run<MFMA, CVT>("older MFMA | younger CVT");
+  run<MIXF, IDLE>("MIXF (v_fma_mix_f32) alone");
+  run<MFMA, MIXF>("older MFMA | younger MIXF");
+  run<CVTS, IDLE>("CVTS (cvt_f16_f32 / cvt_f32_f16) alone");
+  run<MFMA, CVTS>("older MFMA | younger CVTS");
+  run<PKMUL, IDLE>("PKMUL alone");
+  run<MFMA, PKMUL>("older MFMA | younger PKMUL");
+  run<PKMUL, MFMA>("older PKMUL | younger MFMA");
+  run<PERM, IDLE>("PERM alone");
+  run<MFMA, PERM>("older MFMA | younger PERM");
+  run<SWAP, IDLE>("SWAP (permlane32_swap) alone");
+  run<MFMA, SWAP>("older MFMA | younger SWAP");
   run<LDSRW, IDLE>("LDSRW alone");
   run<LDSRW, MFMA>("older LDSRW | younger MFMA");
   run<MFMA, LDSRW>("older MFMA | younger LDSRW");
