@@ -40,7 +40,9 @@
     unsigned long long* o_ = (args_).stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (wave_)) * FMD_NSTAMP; \
     for (int k_ = 0; k_ < FMD_NSTAMP; ++k_) o_[k_] = ts_[k_];                                                \
   }
+#define FMD_DBG_SKIP(args_, bit_) (((args_).dbg >> (bit_)) & 1)
 #else
+#define FMD_DBG_SKIP(args_, bit_) false
 #define FMD_STAMP_DECL
 #define FMD_STAMP_START
 #define FMD_MARK(k)
@@ -85,6 +87,7 @@ struct EdgeArgs {
   int max_beads;           // the caller's bound on beads per molecule: what the dynamic LDS was sized for
 #ifdef FMD_PHASE_STAMPS
   unsigned long long* stamps;  // diagnostic build (make stamps) only: [workgroup][8 waves][FMD_NSTAMP] cycle totals
+  int dbg;                     // diagnostic build only: bit 0 = consumers skip their A-B work, bit 1 = producers skip staging
 #endif
 };
 

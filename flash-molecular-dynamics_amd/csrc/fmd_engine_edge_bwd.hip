@@ -132,20 +132,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         gd_nx = gd_n;
         fetch(t_fetch);
         f32x16 z1 = zero16(), p1 = zero16();
-#pragma unroll
-        for (int s = 0; s < NS0; ++s) {
-          f32x4 c0, c1;
-          if (!SHARE) {
-            c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
-            c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
-          }
-          // z  = C G0 + b0,            G0 = W0 raw
-          // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
-          f16x8 bh, bl, ph, pl;
-          if (SHARE) {  // p accumulates Gc = Wc raw
-            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
-            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
-            bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
+        if (SHARE) {
+          // shared fragments: p accumulates Gc = Wc raw.  The fragments of k-step s+1 are requested before the MFMAs
+          // of k-step s (an LDS round trip per k-step would otherwise sit in front of every group of MFMAs).
+          auto frag_rd = [&](int s_, int rec) {
+            const int blk = min(2 * s_ + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            return *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + rec) * 32 + c32) * 4);
+          };
+          f16x8 bh = frag_rd(0, 0), bl = frag_rd(0, 1);
+          static_for<0, NS0>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 nh = bh, nl = bl;
+            if constexpr (s + 1 < NS0) { nh = frag_rd(s + 1, 0); nl = frag_rd(s + 1, 1); }
             if (HALF) {  // W16A16: the second record holds f16(raw (d - centre)); no cancellation-prone Wc form
               z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
@@ -153,12 +151,22 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               mfma_merged<false>(a0h[s], a0l[s], bh, bl, z1);
               mfma_merged<false>(ach[s], acl[s], bh, bl, p1);
             }
-          } else {
+            bh = nh; bl = nl;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS0; ++s) {
+            // z  = C G0 + b0,            G0 = W0 raw
+            // z' = 2 gamma C G1 + C' G0, G1 = W0 (raw diff)
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
+            f16x8 bh, bl, ph, pl;
             rbf_fragments<true, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
             mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, z1);
             mfma_merged<HALF>(a0h[s], a0l[s], ph, pl, p1);
+            __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
           }
-          __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
         }
         // z' = dz/dd = 2 gamma C G1 + C' G0; in the shared-Gaussian form G1 = (d - c0) G0 - Gc, so
         // z' = (2 gamma C (d - c0) + C') G0 - 2 gamma C Gc
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       __syncthreads();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
-        compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+        if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
         __syncthreads();     // B(t)
         FMD_MARK(1)
@@ -344,21 +352,12 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         __syncthreads();  // ... and consumed
         share_fragments();
       }
-      __syncthreads();  // A(first)
-      FMD_MARK(11)
-      for (int t = T0; t < ntiles; t += S) {
-        fetch_d(t + 2 * S);  // for the fragments written after C(t)
-        if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
-          __syncthreads();  // B(t)
-          __syncthreads();  // C(t)
-          if (SHARE) share_fragments();
-          __syncthreads();  // D(t)
-          __syncthreads();  // A(t+S)
-          continue;
-        }
+      // gW of the tile X holds.  It is formed right after the refill's gathers have landed -- between C and D of the
+      // PREVIOUS tile, where the consumers would otherwise wait for the producers' u GEMM -- and stored after B.
+      f16x2 gwh[8], gwl[8];
+      auto form_gw = [&]() {
         // gW = x1[i] g[j] + x1[j] g[i], split two values at a time: gwh[p] = hi halves of entries 2p, 2p+1,
         // gwl[p] = their lo halves
-        f16x2 gwh[8], gwl[8];
 #pragma unroll
         for (int p2 = 0; p2 < 8; ++p2) {
           const int r = 2 * p2;
@@ -372,6 +371,22 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
 #pragma unroll
         for (int p2 = 0; p2 < 8; ++p2) asm volatile("" : "+v"(gwh[p2]), "+v"(gwl[p2]));  // ahead of the MFMAs
+      };
+      form_gw();  // first tile
+      __syncthreads();  // A(first)
+      FMD_MARK(11)
+      for (int t = T0; t < ntiles; t += S) {
+        fetch_d(t + 2 * S);  // for the fragments written after C(t)
+        if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
+          __syncthreads();  // B(t)
+          __syncthreads();  // C(t)
+          if (SHARE) share_fragments();
+          __syncthreads();  // D(t)
+          __syncthreads();  // A(t+S)
+          continue;
+        }
+        f32x16 fl = zero16();
+        if (!FMD_DBG_SKIP(a, 0)) {
         FMD_MARK(0)
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
@@ -394,7 +409,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           });
         }
-        f32x16 fl;
 #pragma unroll
         for (int r = 0; r < 16; ++r) fl[r] = acc1[r];
         asm volatile("" : "+v"(fl));  // L1 (and its LDS reads) complete
@@ -452,6 +466,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_MARK(5)
         fetch_meta(t + 2 * S);
         FMD_MARK(6)
+        }
         __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(2)
 #pragma unroll
@@ -473,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // the producers read fragments only while staging (between A and B): the tile they stage in the
         // next iteration, t + 2S, is written here
         if (SHARE) share_fragments();
+        form_gw();  // tile t+S
         FMD_MARK(7)
         __syncthreads();  // D(t)
         FMD_MARK(8)

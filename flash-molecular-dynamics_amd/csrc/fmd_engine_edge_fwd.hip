@@ -84,18 +84,33 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         const int nb = min(t_next * 32, last_base);
         d_n = pdist[nb + c32];
         c_n = pcut[nb + c32];
-        f32x16 acc1 = zero16();
+        f32x16 acc1 = zero16();  // C is a per-pair (per-lane) scalar: applied to the sums
+        if (SH) {
+          // the fragments of k-step s+1 are requested before the MFMAs of k-step s
+          auto frag_rd = [&](int s_, int rec) {
+            const int blk = min(2 * s_ + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            return *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + rec) * 32 + c32) * 4);
+          };
+          f16x8 bh = frag_rd(0, 0), bl = bh;
+          if (!HALF) bl = frag_rd(0, 1);
+          static_for<0, NS0>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 nh = bh, nl = bl;
+            if constexpr (s + 1 < NS0) {
+              nh = frag_rd(s + 1, 0);
+              if (!HALF) nl = frag_rd(s + 1, 1);
+            }
+            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
+            bh = nh; bl = nl;
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
 #pragma unroll
-        for (int s = 0; s < NS0; ++s) {
-          f16x8 bh, bl, ph, pl;  // C is a per-pair (per-lane) scalar: applied to the sums
-          if (SH) {
-            const int blk = min(2 * s + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
-            bh = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4);
-            if (!HALF) bl = *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4);
-          } else {
+          for (int s = 0; s < NS0; ++s) {
+            f16x8 bh, bl, ph, pl;
             rbf_fragments<false, HALF>(d, gl, cen[SH ? 0 : 2 * s], cen[SH ? 0 : 2 * s + 1], bh, bl, ph, pl);
+            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
           }
-          mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -179,16 +179,17 @@ int ensure_kernel_attrs() {
 
 #ifdef FMD_PHASE_STAMPS
 unsigned long long* g_stamps = nullptr;   // diagnostic build only
-int g_stamp_block = -1, g_stamp_fwd = 0;  // which launch writes them
+int g_stamp_block = -1, g_stamp_fwd = 0, g_stamp_dbg = 0;  // which launch writes them; role-skip bits
 #endif
 
 }  // namespace
 
 #ifdef FMD_PHASE_STAMPS
-extern "C" int fmd_debug_set_stamps(void* device_buffer, int block, int fwd) {
+extern "C" int fmd_debug_set_stamps(void* device_buffer, int block, int fwd, int dbg) {
   g_stamps = reinterpret_cast<unsigned long long*>(device_buffer);
   g_stamp_block = block;
   g_stamp_fwd = fwd;
+  g_stamp_dbg = dbg;
   return FMD_OK;
 }
 #endif
@@ -331,6 +332,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
 #ifdef FMD_PHASE_STAMPS
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
+    ea.dbg = ea.stamps ? g_stamp_dbg : 0;
 #endif
     if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, n_mol, s);
     return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, n_mol, s);

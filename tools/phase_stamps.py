@@ -22,6 +22,7 @@ ap.add_argument("--block", type=int, default=1)
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--beads", type=int, default=269)
 ap.add_argument("--precision", default="f32")
+ap.add_argument("--dbg", type=int, default=0, help="bit 0: consumers skip their A-B work, bit 1: producers skip staging (timing only, wrong results)")
 args = ap.parse_args()
 dev = "cuda:0"
 torch.manual_seed(0)
@@ -37,11 +38,11 @@ lib = _ffi.lib()
 lib.fmd_debug_set_stamps.restype = ctypes.c_int
 for _ in range(3):
     eng.energy_forces(pos, types, ptr, args.beads)
-lib.fmd_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()), args.block, 1 if args.fwd else 0)
+lib.fmd_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()), args.block, 1 if args.fwd else 0, args.dbg)
 eng.energy_forces(pos, types, ptr, args.beads)
 torch.cuda.synchronize()
-lib.fmd_debug_set_stamps(None, -1, 0)
-st = eng.check_status()
+lib.fmd_debug_set_stamps(None, -1, 0, 0)
+st = eng.status.tolist()
 tiles_per_wg = (st[2] / args.batch * 1.065 / 32) / (n_wg / args.batch)   # pairs + ~6.5 % pad entries
 t = buf[: n_wg * 8 * NST].view(n_wg, 8, NST).double().cpu()
 for name, sl in (("consumers (waves 0-3)", slice(0, 4)), ("producers (waves 4-7)", slice(4, 8))):
