@@ -146,6 +146,15 @@ class FusedSchNetEngine:
         self._bound_key = None      # (mol_ptr identity) whose caller-supplied bead bound has been validated
         self._since_check = 0       # force evaluations since the status words were last read
 
+    @classmethod
+    def from_state_dict(cls, sd, device="cuda", prefix: str = "", **kw):
+        """Engine from a ``state_dict`` keyed by the reference's parameter names (a dict, an ``.npz`` or a
+        weights-only ``torch.load`` file; see ``schnet.model_from_state_dict``).  Raises ValueError when the model is
+        outside the engine's envelope (hidden = filters = 128, 2 <= num_rbf <= 64, 2-3 output linears)."""
+        from .schnet import model_from_state_dict
+
+        return cls(model_from_state_dict(sd, prefix).to(device).eval(), **kw)
+
     def _workspace(self, n_mol, n_nodes, cap):
         key = (n_mol, n_nodes, cap)
         if self._ws_key != key:

@@ -366,6 +366,55 @@ class Batch:
         self.max_beads_per_mol = max_beads_per_mol
 
 
+def _state_dict_from_file(path: str) -> dict:
+    """Name -> tensor from a ``state_dict`` file.  ``.npz``: numpy arrays under the reference's parameter names;
+    anything else: ``torch.load(..., weights_only=True)`` -- a plain ``state_dict`` (or ``{"state_dict": ...}``), never
+    a pickled module (the reference's published ``model_and_prior.pt`` is one: it needs the ``mlcg`` package to
+    unpickle and is out of scope; export ``model.state_dict()`` where that package exists)."""
+    if path.endswith(".npz"):
+        import numpy as np
+
+        z = np.load(path)  # allow_pickle stays False
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
+        raise ValueError(f"{path}: expected a state_dict (name -> tensor)")
+    return sd
+
+
+def model_from_state_dict(sd, prefix: str = "") -> StandardSchNet:
+    """Row N4 (the buildable part): a ``StandardSchNet`` from a state_dict keyed by the reference's parameter names
+    (reference models/schnet.py:778-841; the same names this mirror uses: ``embedding_layer.weight``,
+    ``rbf_layer.offset`` / ``.coeff``, ``interaction_blocks.<l>.conv.{lin1,lin2,filter_network.layers.<k>}``,
+    ``interaction_blocks.<l>.lin``, ``output_network.layers.<k>``).  Hyper-parameters are read off the shapes; the
+    cutoff is the last Gaussian centre (``GaussianBasis.offset = linspace(cutoff_lower, cutoff_upper)``,
+    radial_basis/gaussian.py:71-75).  ``sd``: a dict or a path (``.npz`` or a weights-only ``torch.load`` file);
+    ``prefix``: e.g. ``"model."`` when the SchNet sits inside a wrapper such as ``GradientsOut``."""
+    if isinstance(sd, str):
+        sd = _state_dict_from_file(sd)
+    sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    need = ["embedding_layer.weight", "rbf_layer.offset", "interaction_blocks.0.conv.lin1.weight"]
+    missing = [k for k in need if k not in sd]
+    if missing:
+        raise KeyError(f"state_dict lacks {missing}: not a StandardSchNet under the reference's names")
+    emb = sd["embedding_layer.weight"]
+    offset = sd["rbf_layer.offset"].flatten()
+    n_blocks = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("interaction_blocks."))
+    filt = sd["interaction_blocks.0.conv.filter_network.layers.0.weight"]
+    out_idx = sorted({int(k.split(".")[2]) for k in sd if k.startswith("output_network.layers.") and k.endswith(".weight")})
+    widths = [int(sd[f"output_network.layers.{i}.weight"].shape[0]) for i in out_idx[:-1]]
+    if float(offset[0]) != 0.0:
+        raise ValueError("rbf_layer.offset does not start at 0: cutoff_lower != 0 is outside this build")
+    rc = float(offset[-1])
+    m = StandardSchNet(GaussianBasis(CosineCutoff(0.0, rc), int(offset.numel())), CosineCutoff(0.0, rc), widths,
+                       hidden_channels=int(emb.shape[1]), embedding_size=int(emb.shape[0]),
+                       num_filters=int(filt.shape[0]), num_interactions=n_blocks)
+    m.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()}, strict=True)
+    return m
+
+
 def model_from_params(p: dict) -> StandardSchNet:
     """Build a StandardSchNet from the flat weight dict used by the fixtures (tests/golden)."""
     rc = p["cutoff"]

@@ -189,6 +189,19 @@ def _run_reference(model, pos, types_, ptr, dtype):
     return data.out["SchNet"]["energy"].detach(), data.out["SchNet"]["forces"].detach()
 
 
+def case_config1(model, p, so, rc):
+    """BASELINE configs[0] at its stated size: 4 molecules x 269 beads, the reference's --disable_optim path."""
+    pos, types_, ptr = so.synth_batch(4, 269, rc)
+    e64, f64 = _run_reference(model, pos, types_, ptr, torch.float64)
+    e32, f32 = _run_reference(model, pos, types_, ptr, torch.float32)
+    oe, of = so.schnet_energy_forces(so.params_to(p, torch.float64), pos.double(), types_, ptr)
+    assert float((of - f64).norm() / f64.norm()) < 1e-12 and float((oe - e64).abs().max() / e64.abs().max()) < 1e-12
+    print(f"[1enh x4] reference fp32 vs fp64: forces {float((f32.double() - f64).norm() / f64.norm()):.2e}")
+    np.savez_compressed(
+        os.path.join(GOLD, "case_1enh_4x269.npz"), pos=pos.numpy(), types=types_.numpy(), ptr=ptr.numpy(),
+        energy_ref64=e64.numpy(), forces_ref64=f64.numpy(), energy_ref32=e32.numpy(), forces_ref32=f32.numpy())
+
+
 def main():
     sys.path.insert(0, "/root/reference/src")
     _install_standins()
@@ -201,6 +214,9 @@ def main():
     #      perturbed to +-0.1 so that every bias term is exercised
     model = _reference_model(R, L, rc, (128, 64))
     p = _params_from_reference(model, rc, bias_seed=11)
+    if "--only-config1" in sys.argv:   # adds case_1enh_4x269.npz without rewriting the other fixtures
+        case_config1(model, p, so, rc)
+        return
     np.savez_compressed(os.path.join(GOLD, "weights_L3_R50.npz"), **flatten_params(p))
 
     # ---- case A: 3 small molecules (37 beads), all per-stage tensors, fp64 reference
@@ -255,6 +271,7 @@ def main():
     np.savez_compressed(
         os.path.join(GOLD, "case_ragged.npz"), pos=pos.numpy(), types=types_.numpy(),
         ptr=ptr.numpy(), energy_ref64=e64.numpy(), forces_ref64=f64.numpy())
+    case_config1(model, p, so, rc)
     print("golden fixtures written to", GOLD)
 
 

@@ -92,10 +92,11 @@ print("REL", re, rf)
 """
 
 
-@pytest.mark.parametrize("case", ["case_small_3x37", "case_ragged"])
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_ragged", "case_1enh_4x269"])
 def test_disable_optim_pytorch_path_on_cpu_matches_reference(case):
     """BASELINE config 1: all MLCG_USE_* = 0 -> plain PyTorch ops on the CPU, checked against the
-    reference's fp64 vectors (budget 1e-4; fp32 lands near 1e-6)."""
+    reference's fp64 vectors (budget 1e-4; fp32 lands near 1e-6).  ``case_1enh_4x269`` is the configuration at its
+    stated size: 4 molecules x 269 beads."""
     env = dict(os.environ, MLCG_USE_TRITON_MESSAGE_PASSING="0", MLCG_USE_FUSED_RBF="0",
                MLCG_USE_FUSED_TANH_LINEAR="0", MLCG_USE_CSR="0", MLCG_USE_SRC_CSR_GRAD_X="0")
     out = subprocess.run([sys.executable, "-c", _CPU_PATH % {"root": ROOT, "case": case}], env=env,
@@ -167,3 +168,42 @@ def test_trajectory_writer_layout_and_checkpoint_resume(tmp_path):
     sim2 = simulate.LangevinSimulation(ff, pos, masses, beta, n_atoms, dt=0.004, use_hip=False)
     assert sim2.load_checkpoint(f"{base}_checkpoint_0001.pt") == 2
     assert torch.equal(sim2.x, frames[-1][0]) and torch.equal(sim2.v, frames[-1][4])
+
+
+def test_state_dict_loaders_row_n4(tmp_path, golden_dir):
+    """Row N4, the buildable part: a model rebuilt from a state_dict keyed by the reference's parameter names -- from
+    a dict, from an .npz and from a weights-only torch.load file, bare or inside a wrapper ("model." prefix) -- is the
+    model the fixtures were produced with (same energies / forces on the CPU path as the reference's vectors); a
+    pickled module is refused (the published model_and_prior.pt is one: out of scope)."""
+    import numpy as np
+    import torch
+
+    from oracle import schnet_oracle as so
+    import flashmd_amd.schnet as S
+
+    S_gates = (S.USE_TRITON_MESSAGE_PASSING, S.USE_FUSED_RBF, S.USE_FUSED_TANH_LINEAR, S.USE_CSR, S.USE_SRC_CSR_GRAD_X)
+    p = so.params_from_npz(os.path.join(golden_dir, "weights_L3_R50.npz"))
+    ref_model = S.model_from_params(p)
+    sd = ref_model.state_dict()
+    assert "interaction_blocks.2.conv.filter_network.layers.2.weight" in sd and "rbf_layer.offset" in sd
+    np.savez(tmp_path / "sd.npz", **{k: v.numpy() for k, v in sd.items()})
+    torch.save(sd, tmp_path / "sd.pt")
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, tmp_path / "wrapped.pt")
+    torch.save(ref_model, tmp_path / "module.pt")
+    models = [S.model_from_state_dict(sd), S.model_from_state_dict(str(tmp_path / "sd.npz")),
+              S.model_from_state_dict(str(tmp_path / "sd.pt")),
+              S.model_from_state_dict(str(tmp_path / "wrapped.pt"), prefix="model.")]
+    for m in models:
+        assert m.rbf_layer.cutoff.cutoff_upper == 5.0 and m.rbf_layer.num_rbf == 50 and len(m.interaction_blocks) == 3
+        for (ka, va), (kb, vb) in zip(sd.items(), m.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb), ka
+    with pytest.raises(Exception):   # weights_only refuses a pickled nn.Module
+        S.model_from_state_dict(str(tmp_path / "module.pt"))
+    with pytest.raises(KeyError):
+        S.model_from_state_dict({"foo.weight": torch.zeros(1)})
+    if not any(S_gates[:1] + S_gates[2:]) and S_gates[1] != "1":   # gates off in this process: evaluate on the CPU path
+        z = np.load(os.path.join(golden_dir, "case_small_3x37.npz"))
+        pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
+        data = S.GradientsOut(models[1]).eval()(S.Batch(pos.clone(), types, ptr))
+        f = data.out["SchNet"]["forces"].double().numpy()
+        assert np.linalg.norm(f - z["forces_ref64"]) / np.linalg.norm(z["forces_ref64"]) < 1e-5
