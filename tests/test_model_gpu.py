@@ -532,3 +532,20 @@ def test_fused_engine_empty_molecule_in_batch(params):
     assert int(eng.status[0]) == 0
     assert float(e3[1]) == 0.0
     assert torch.equal(e3[[0, 2]], e2) and torch.equal(f3, f2)
+
+
+def test_engine_from_state_dict_file(params, golden_dir, tmp_path):
+    """Row N4: FusedSchNetEngine.from_state_dict on an .npz keyed by the reference's parameter names gives the
+    reference's energies and forces."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    sd = S.model_from_params(params).state_dict()
+    path = str(tmp_path / "sd.npz")
+    np.savez(path, **{k: v.numpy() for k, v in sd.items()})
+    eng = engine.FusedSchNetEngine.from_state_dict(path, device=DEV)
+    z = np.load(os.path.join(golden_dir, "case_1enh_2x269.npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]).to(DEV) for k in ("pos", "types", "ptr"))
+    e, f = eng.energy_forces(pos, types, ptr, 269)
+    re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+    assert re < 2e-5 and rf < 2e-5
