@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       __syncthreads();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < ntiles; t += S) {
-        compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
         FMD_MARK(0)
         __syncthreads();     // B(t)
         FMD_MARK(1)
