@@ -42,11 +42,15 @@ __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_fwd_kernel(
 
 // grad wrt distance, then scattered onto the two end points with float atomics (the reference
 // uses index_add_, equally unordered).
+// SCATTER = true: float atomics onto gpos (any edge list).  SCATTER = false: the per-edge vector
+// gd (r_dst - r_src) / d is stored to edge_vec[E][4] and rbf_gather_kernel sums it per node over the caller's CSR
+// indices -- no atomics, fixed summation order.
+template <bool SCATTER>
 __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ esrc, const int64_t* __restrict__ edst,
     const float* __restrict__ centers, float gamma, float rc, int64_t n_edges, int n_rbf,
     const float* __restrict__ dist, const float* __restrict__ gdist, const float* __restrict__ grbf,
-    float* __restrict__ gpos) {
+    float* __restrict__ gpos, f32x4* __restrict__ edge_vec) {
   // grad_rbf is [E, R] row-major: the wave's 64 x R block is read coalesced and staged in LDS ([64][R + 1]: odd
   // stride, conflict-free), then lane e sums its own row against d(rbf)/dd.  (The first version added every
   // element with an LDS float atomic: ~3 cycles per lane on this chip, 10x the cost of the staging.)
@@ -92,6 +96,10 @@ __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
                 dz = pos[3 * t + 2] - pos[3 * s + 2];
     const float inv = gd / fmaxf(d, 1e-8f);  // clamp as cfconv_kernels.py:1697
     const float gx = dx * inv, gy = dy * inv, gz = dz * inv;
+    if (!SCATTER) {
+      edge_vec[e] = f32x4{gx, gy, gz, 0.f};
+      return;
+    }
     atomicAdd(&gpos[3 * t], gx);
     atomicAdd(&gpos[3 * t + 1], gy);
     atomicAdd(&gpos[3 * t + 2], gz);
@@ -99,6 +107,30 @@ __global__ __launch_bounds__(RBF_WAVES * 64) void rbf_bwd_kernel(
     atomicAdd(&gpos[3 * s + 1], -gy);
     atomicAdd(&gpos[3 * s + 2], -gz);
   }
+}
+
+// gpos[n] = sum_{e: dst(e) = n} v_e - sum_{e: src(e) = n} v_e over the two CSR indices (perm[k] = edge id).  One wave
+// per node: lanes stride over the segment, 16-byte gathers, one xor-tree reduction per component.
+__global__ __launch_bounds__(256) void rbf_gather_kernel(const f32x4* __restrict__ edge_vec,
+                                                         const int64_t* __restrict__ dst_ptr,
+                                                         const int64_t* __restrict__ dst_perm,
+                                                         const int64_t* __restrict__ src_ptr,
+                                                         const int64_t* __restrict__ src_perm, int64_t n_nodes,
+                                                         float* __restrict__ gpos) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= n_nodes) return;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  for (int64_t k = dst_ptr[n] + lane; k < dst_ptr[n + 1]; k += 64) {
+    const f32x4 v = edge_vec[dst_perm[k]];
+    ax += v[0]; ay += v[1]; az += v[2];
+  }
+  for (int64_t k = src_ptr[n] + lane; k < src_ptr[n + 1]; k += 64) {
+    const f32x4 v = edge_vec[src_perm[k]];
+    ax -= v[0]; ay -= v[1]; az -= v[2];
+  }
+  ax = fmd_wave_sum(ax); ay = fmd_wave_sum(ay); az = fmd_wave_sum(az);
+  if (lane == 0) { gpos[3 * n] = ax; gpos[3 * n + 1] = ay; gpos[3 * n + 2] = az; }
 }
 
 }  // namespace
@@ -130,9 +162,36 @@ extern "C" int fmd_distance_rbf_cutoff_bwd(const float* pos, const int64_t* edge
   const int64_t nblk = (n_edges + RBF_WAVES * 64 - 1) / (RBF_WAVES * 64);
   const int kc = (int)(n_rbf < RBF_KC ? n_rbf : RBF_KC);
   const size_t lds = grad_rbf ? (size_t)RBF_WAVES * 64 * (kc | 1) * sizeof(float) : 0;
-  rbf_bwd_kernel<<<(unsigned)nblk, RBF_WAVES * 64, lds, s>>>(pos, edge_src, edge_dst, centers, gamma,
-                                                         cutoff, n_edges, (int)n_rbf, dist, grad_dist,
-                                                         grad_rbf, grad_pos);
+  rbf_bwd_kernel<true><<<(unsigned)nblk, RBF_WAVES * 64, lds, s>>>(pos, edge_src, edge_dst, centers, gamma,
+                                                               cutoff, n_edges, (int)n_rbf, dist, grad_dist,
+                                                               grad_rbf, grad_pos, nullptr);
+  FMD_CHECK_LAUNCH();
+  return FMD_OK;
+}
+
+extern "C" int fmd_distance_rbf_cutoff_bwd_csr(const float* pos, const int64_t* edge_src, const int64_t* edge_dst,
+                                               const float* centers, float gamma, float cutoff, int64_t n_edges,
+                                               int64_t n_rbf, int64_t n_nodes, const float* dist,
+                                               const float* grad_dist, const float* grad_rbf,
+                                               const int64_t* dst_ptr, const int64_t* dst_perm,
+                                               const int64_t* src_ptr, const int64_t* src_perm, void* edge_vec,
+                                               float* grad_pos, void* stream) {
+  if (n_edges < 0 || n_rbf <= 0 || n_nodes < 0 || !grad_pos) return FMD_EINVAL;
+  hipStream_t s = fmd_stream(stream);
+  if (n_edges == 0) return hipMemsetAsync(grad_pos, 0, sizeof(float) * 3 * n_nodes, s) == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+  if (!pos || !edge_src || !edge_dst || !centers || !dist || !dst_ptr || !dst_perm || !src_ptr || !src_perm ||
+      !edge_vec || (reinterpret_cast<uintptr_t>(edge_vec) & 15))
+    return FMD_EINVAL;
+  const int64_t nblk = (n_edges + RBF_WAVES * 64 - 1) / (RBF_WAVES * 64);
+  const int kc = (int)(n_rbf < RBF_KC ? n_rbf : RBF_KC);
+  const size_t lds = grad_rbf ? (size_t)RBF_WAVES * 64 * (kc | 1) * sizeof(float) : 0;
+  rbf_bwd_kernel<false><<<(unsigned)nblk, RBF_WAVES * 64, lds, s>>>(
+      pos, edge_src, edge_dst, centers, gamma, cutoff, n_edges, (int)n_rbf, dist, grad_dist, grad_rbf, nullptr,
+      reinterpret_cast<f32x4*>(edge_vec));
+  FMD_CHECK_LAUNCH();
+  if (n_nodes > 0)
+    rbf_gather_kernel<<<(unsigned)((n_nodes + 3) / 4), 256, 0, s>>>(reinterpret_cast<const f32x4*>(edge_vec), dst_ptr,
+                                                                dst_perm, src_ptr, src_perm, n_nodes, grad_pos);
   FMD_CHECK_LAUNCH();
   return FMD_OK;
 }

@@ -24,6 +24,7 @@ SIGNATURES = {
     "fmd_radius_graph_fill": (I32, [P, P, I64, I64, I64, F32, P, P, P, P]),
     "fmd_distance_rbf_cutoff_fwd": (I32, [P, P, P, P, F32, F32, I64, I64, P, P, P]),
     "fmd_distance_rbf_cutoff_bwd": (I32, [P, P, P, P, F32, F32, I64, I64, I64, P, P, P, P, P]),
+    "fmd_distance_rbf_cutoff_bwd_csr": (I32, [P, P, P, P, F32, F32, I64, I64, I64, P, P, P, P, P, P, P, P, P, P]),
     "fmd_build_csr_workspace_bytes": (I64, [I64, I64]),
     "fmd_build_csr": (I32, [P, I64, I64, P, P, P, P]),
     "fmd_csr_cfconv_fwd": (I32, [P, P, I32, P, P, P, P, I64, I64, F32, P, P]),

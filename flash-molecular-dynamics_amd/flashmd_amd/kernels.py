@@ -137,31 +137,49 @@ class FusedDistanceGaussianRBFCutoffFunction(torch.autograd.Function):
     """reference kernels/cfconv_kernels.py:1659-1735"""
 
     @staticmethod
-    def forward(ctx, pos, edge_src, edge_dst, centers, gamma, cutoff_upper):
+    def forward(ctx, pos, edge_src, edge_dst, centers, gamma, cutoff_upper, csr=None):
         distances, rbf = fused_distance_gaussian_rbf_cutoff(pos, edge_src, edge_dst, centers, gamma,
                                                             cutoff_upper)
         ctx.save_for_backward(pos, edge_src, edge_dst, centers, distances)
         ctx.gamma, ctx.cutoff_upper = gamma, cutoff_upper
+        ctx.csr = csr  # optional (dst_ptr, dst_perm, src_ptr, src_perm): atomic-free backward
         return distances, rbf
 
     @staticmethod
     def backward(ctx, grad_distances, grad_rbf):
         pos, edge_src, edge_dst, centers, distances = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         grad_pos = torch.empty_like(pos)
         gd = grad_distances.contiguous() if grad_distances is not None else None
         gr = grad_rbf.contiguous() if grad_rbf is not None else None
+        if ctx.csr is not None:
+            dst_ptr, dst_perm, src_ptr, src_perm = ctx.csr
+            edge_vec = torch.empty(edge_src.shape[0], 4, device=pos.device, dtype=torch.float32)
+            call("fmd_distance_rbf_cutoff_bwd_csr", ptr(pos), ptr(edge_src), ptr(edge_dst), ptr(centers),
+                 float(ctx.gamma), float(ctx.cutoff_upper), edge_src.shape[0], centers.shape[0], pos.shape[0],
+                 ptr(distances), ptr(gd), ptr(gr), ptr(dst_ptr), ptr(dst_perm), ptr(src_ptr), ptr(src_perm),
+                 ptr(edge_vec), ptr(grad_pos), stream())
+            return grad_pos, None, None, None, None, None, None
         call("fmd_distance_rbf_cutoff_bwd", ptr(pos), ptr(edge_src), ptr(edge_dst), ptr(centers),
              float(ctx.gamma), float(ctx.cutoff_upper), edge_src.shape[0], centers.shape[0],
              pos.shape[0], ptr(distances), ptr(gd), ptr(gr), ptr(grad_pos), stream())
-        return grad_pos, None, None, None, None, None
+        return grad_pos, None, None, None, None, None, None
 
 
 def fused_distance_gaussian_rbf_cutoff_autograd(pos, edge_src, edge_dst, centers, gamma: float,
                                                 cutoff_upper: float) -> tuple:
     return FusedDistanceGaussianRBFCutoffFunction.apply(pos, edge_src, edge_dst, centers, gamma,
                                                         cutoff_upper)
+
+
+def fused_distance_gaussian_rbf_cutoff_with_csr(pos, edge_src, edge_dst, centers, gamma: float, cutoff_upper: float,
+                                                dst_ptr, dst_perm, src_ptr, src_perm) -> tuple:
+    """Not in the reference's surface: the same operator for a caller that already holds both CSR indices of the edge
+    list (SchNet.forward does); its backward then sums the per-edge gradient by node over those indices instead of
+    issuing six global float atomics per edge."""
+    return FusedDistanceGaussianRBFCutoffFunction.apply(pos, edge_src, edge_dst, centers, gamma, cutoff_upper,
+                                                        (dst_ptr, dst_perm, src_ptr, src_perm))
 
 
 # ==================================================================================================

@@ -263,18 +263,8 @@ class SchNet(torch.nn.Module):
         x = self.embedding_layer(data.atom_types)
         cutoff_upper = self.rbf_layer.cutoff.cutoff_upper
         edge_index = self._edges(data, cutoff_upper)
-        if USE_FUSED_RBF == "1":  # reference :261-283
-            _need_gpu(data.pos, "SchNet fused RBF")
-            if self._cached_gamma is None:
-                self._cached_gamma = self.rbf_layer.coeff.item()
-            distances, rbf_expansion = K.fused_distance_gaussian_rbf_cutoff_autograd(
-                data.pos.contiguous(), edge_index[0].contiguous(), edge_index[1].contiguous(),
-                self.rbf_layer.offset, self._cached_gamma, cutoff_upper)
-        else:  # reference :287-299
-            dr = data.pos[edge_index[1]] - data.pos[edge_index[0]]
-            distances = dr.norm(p=2, dim=1)
-            rbf_expansion = self.rbf_layer(distances)
-
+        # the CSR indices are built first (the reference builds them after the RBF expansion, :309-334): with both at
+        # hand the fused RBF operator's backward needs no float atomics
         csr_data = None
         if USE_CSR or USE_SRC_CSR_GRAD_X:  # reference :309-334
             _need_gpu(x, "SchNet CSR")
@@ -284,6 +274,24 @@ class SchNet(torch.nn.Module):
                 csr_data["dst_ptr"], csr_data["csr_perm"] = K.build_csr_index(edge_dst, x.shape[0])
             if USE_SRC_CSR_GRAD_X:
                 csr_data["src_ptr"], csr_data["src_perm"] = K.build_src_csr_index(edge_src, x.shape[0])
+
+        if USE_FUSED_RBF == "1":  # reference :261-283
+            _need_gpu(data.pos, "SchNet fused RBF")
+            if self._cached_gamma is None:
+                self._cached_gamma = self.rbf_layer.coeff.item()
+            if csr_data is not None and "dst_ptr" in csr_data and "src_ptr" in csr_data:
+                distances, rbf_expansion = K.fused_distance_gaussian_rbf_cutoff_with_csr(
+                    data.pos.contiguous(), csr_data["edge_src"], csr_data["edge_dst"], self.rbf_layer.offset,
+                    self._cached_gamma, cutoff_upper, csr_data["dst_ptr"], csr_data["csr_perm"],
+                    csr_data["src_ptr"], csr_data["src_perm"])
+            else:
+                distances, rbf_expansion = K.fused_distance_gaussian_rbf_cutoff_autograd(
+                    data.pos.contiguous(), edge_index[0].contiguous(), edge_index[1].contiguous(),
+                    self.rbf_layer.offset, self._cached_gamma, cutoff_upper)
+        else:  # reference :287-299
+            dr = data.pos[edge_index[1]] - data.pos[edge_index[0]]
+            distances = dr.norm(p=2, dim=1)
+            rbf_expansion = self.rbf_layer(distances)
 
         for block in self.interaction_blocks:  # reference :336-341
             x = x + block(x, edge_index, distances, rbf_expansion, csr_data=csr_data)

@@ -68,6 +68,16 @@ int fmd_distance_rbf_cutoff_bwd(const float* pos, const int64_t* edge_src, const
                                 int64_t n_rbf, int64_t n_nodes, const float* dist,
                                 const float* grad_dist, const float* grad_rbf, float* grad_pos,
                                 void* stream);
+/* The same gradient without float atomics, for callers that hold both CSR indices of the edge list (the reference's
+ * SchNet.forward builds them anyway, models/schnet.py:309-334): an edge pass stores the per-edge vector
+ * gd (r_dst - r_src) / d into edge_vec (n_edges x 16 bytes, 16-byte aligned), a node pass sums it over the dst- and
+ * src-segments (ptr/perm as produced by fmd_build_csr).  Deterministic; grad_pos is fully overwritten. */
+int fmd_distance_rbf_cutoff_bwd_csr(const float* pos, const int64_t* edge_src, const int64_t* edge_dst,
+                                    const float* centers, float gamma, float cutoff, int64_t n_edges,
+                                    int64_t n_rbf, int64_t n_nodes, const float* dist, const float* grad_dist,
+                                    const float* grad_rbf, const int64_t* dst_ptr, const int64_t* dst_perm,
+                                    const int64_t* src_ptr, const int64_t* src_perm, void* edge_vec,
+                                    float* grad_pos, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A3  COO -> CSR bucket sort.  Replaces build_csr_index (kernels/csr_kernels.py:88-169) and

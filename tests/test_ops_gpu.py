@@ -81,6 +81,19 @@ def test_distance_rbf_forward_and_backward(K):
     assert rel(rbf.detach().cpu(), rbf_ref.detach()) < 2e-6
     (gp,) = torch.autograd.grad((d * gd.to(DEV)).sum() + (rbf * gr.to(DEV)).sum(), pg)
     assert rel(gp.cpu(), gp_ref) < 1e-5
+    # the same operator with both CSR indices at hand: backward without float atomics (edge pass + by-node gather),
+    # same values as the fp64 oracle and bit-reproducible from call to call
+    n = pos.shape[0]
+    dst_ptr, dst_perm = K.build_csr_index(dst.to(DEV), n)
+    src_ptr, src_perm = K.build_src_csr_index(src.to(DEV), n)
+    grads = []
+    for _ in range(2):
+        pc = pos.to(DEV).requires_grad_(True)
+        d2, rbf2 = K.fused_distance_gaussian_rbf_cutoff_with_csr(pc, src.to(DEV), dst.to(DEV), centers.to(DEV), gamma,
+                                                                 5.0, dst_ptr, dst_perm, src_ptr, src_perm)
+        assert torch.equal(d2, d) and torch.equal(rbf2, rbf)
+        grads.append(torch.autograd.grad((d2 * gd.to(DEV)).sum() + (rbf2 * gr.to(DEV)).sum(), pc)[0])
+    assert rel(grads[0].cpu(), gp_ref) < 1e-5 and torch.equal(grads[0], grads[1])
     # zero edges: empty outputs (reference cfconv_kernels.py:1630-1631)
     e0 = torch.zeros(0, dtype=torch.int64, device=DEV)
     d0, r0 = K.fused_distance_gaussian_rbf_cutoff(pos.to(DEV), e0, e0, centers.to(DEV), gamma, 5.0)
