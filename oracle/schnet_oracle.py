@@ -11,9 +11,11 @@ Pinning: ``oracle/make_golden.py`` ran the reference's own ``StandardSchNet`` +
 ``tests/golden/`` and wrote its energies/forces there; ``tests/test_oracle.py`` checks this
 restatement against those vectors and against the closed-form cutoff end points the
 reference tests hold (reference ``tests/models/test_cutoff.py:27-42``).
-The W16A16 variant (``w16a16=True``) follows the rounding points listed in SURVEY.md row A9;
-the reference's fp16 Triton path cannot execute in the build container, so that variant is
-"parity unpinned" (it is anchored only on the fp32 oracle it converges to).
+The W16A16 variant (``w16a16=True``) follows the rounding points listed in SURVEY.md row A9 and is
+pinned to the reference's own Triton kernels: ``oracle/make_golden_triton.py`` executed them under
+``TRITON_INTERPRET=1`` (stage vectors ``tests/golden/triton_stages_1x37.npz``: K6 / K7 bit-identical, K4 / K5
+within one fp16 ulp on < 0.3 % of the elements) and the reference's W16A16 model end to end
+(``tests/golden/case_w16a16_ref.npz``); ``tests/test_oracle.py`` checks both.
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference/src/flashmd).
