@@ -332,6 +332,25 @@ __device__ __forceinline__ void mfma_merged(const f16x8& ah, const f16x8& al, co
   }
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
 }
+// Diagnostic build only: the same with one of the small products left out (drop = 1: a_hi b_lo, i.e. the B operand
+// reduced to fp16; drop = 2: a_lo b_hi, the A operand reduced to fp16) -- the "two-product" variants whose force error
+// and time tools/two_product.py reports.  The product path never instantiates this.
+#ifdef FMD_PHASE_STAMPS
+template <bool HALF>
+__device__ __forceinline__ void mfma_merged_drop(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl,
+                                                 f32x16& acc, int drop) {
+  if (!HALF) {
+    if (drop != 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    if (drop != 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+#define FMD_MERGED(HALF_, ah_, al_, bh_, bl_, acc_, drop_) mfma_merged_drop<HALF_>(ah_, al_, bh_, bl_, acc_, drop_)
+#define FMD_DROP(args_, shift_) (((args_).dbg >> (shift_)) & 3)
+#else
+#define FMD_MERGED(HALF_, ah_, al_, bh_, bl_, acc_, drop_) mfma_merged<HALF_>(ah_, al_, bh_, bl_, acc_)
+#define FMD_DROP(args_, shift_) 0
+#endif
 // acc1 += a_hi b_hi ; acc2 += a_hi b_lo + a_lo b_hi
 __device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh,
                                            const f16x8& bl, f32x16& acc1, f32x16& acc2) {

@@ -84,6 +84,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
   FMD_STAMP_DECL
+  const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
+  (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
   if (T0 < ntiles) {  // uniform over the workgroup
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
             } else {
-              mfma_merged<false>(a0h[s], a0l[s], bh, bl, z1);
-              mfma_merged<false>(ach[s], acl[s], bh, bl, p1);
+              FMD_MERGED(false, a0h[s], a0l[s], bh, bl, z1, drop_l0);
+              FMD_MERGED(false, ach[s], acl[s], bh, bl, p1, drop_l0);
             }
             bh = nh; bl = nl;
             __builtin_amdgcn_sched_barrier(0);
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             const f32x4 c1 = *reinterpret_cast<const f32x4*>(cen_l + 16 * s + 8 * h + 4);
             f16x8 bh, bl, ph, pl;
             rbf_fragments<true, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
-            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, z1);
-            mfma_merged<HALF>(a0h[s], a0l[s], ph, pl, p1);
+            FMD_MERGED(HALF, a0h[s], a0l[s], bh, bl, z1, drop_l0);
+            FMD_MERGED(HALF, a0h[s], a0l[s], ph, pl, p1, drop_l0);
             __builtin_amdgcn_sched_barrier(0);  // one k-step of temporaries live at a time
           }
         }
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
               aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
-            mfma_merged<HALF>(ah0, al0, b1h[s], b1l[s], acc1);
+            FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int T0 = FS ? 0 : split;     // its first tile
   const int last_base = (ntiles - 1) * 32;
   FMD_STAMP_DECL
+  const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
+  (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
   if (T0 < ntiles) {  // uniform over the workgroup
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
               nh = frag_rd(s + 1, 0);
               if (!HALF) nl = frag_rd(s + 1, 1);
             }
-            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
+            FMD_MERGED(HALF, a0h[s], a0l[s], bh, bl, acc1, drop_l0);
             bh = nh; bl = nl;
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           for (int s = 0; s < NS0; ++s) {
             f16x8 bh, bl, ph, pl;
             rbf_fragments<false, HALF>(d, gl, cen[SH ? 0 : 2 * s], cen[SH ? 0 : 2 * s + 1], bh, bl, ph, pl);
-            mfma_merged<HALF>(a0h[s], a0l[s], bh, bl, acc1);
+            FMD_MERGED(HALF, a0h[s], a0l[s], bh, bl, acc1, drop_l0);
           }
         }
 #pragma unroll
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
               aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
-            mfma_merged<HALF>(ah0, al0, b1h[s], b1l[s], acc1);
+            FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });

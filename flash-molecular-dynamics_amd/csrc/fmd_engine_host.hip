@@ -332,7 +332,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
 #ifdef FMD_PHASE_STAMPS
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
-    ea.dbg = ea.stamps ? g_stamp_dbg : 0;
+    ea.dbg = (ea.stamps || g_stamp_block == -2) ? g_stamp_dbg : 0;   // block -2: the switches apply to every launch
 #endif
     if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, n_mol, s);
     return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, n_mol, s);
