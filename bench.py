@@ -261,8 +261,12 @@ def main():
         go = S.GradientsOut(model).eval()
         model._engine = eng
 
+        batch_obj = S.Batch(pos, types, ptr, max_beads_per_mol=args.beads)  # collated once, like the reference's
+        # simulation keeps one AtomicData and updates its positions (simulation/base.py:991-1020)
+
         def force_go(x):
-            d = go(S.Batch(x, types, ptr, max_beads_per_mol=args.beads))
+            batch_obj.pos, batch_obj.out = x, {}
+            d = go(batch_obj)
             return d.out["SchNet"]["energy"], d.out["SchNet"]["forces"]
 
         sim.force_fn = force_go
