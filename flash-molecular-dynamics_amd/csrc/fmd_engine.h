@@ -37,7 +37,7 @@
   }
 #define FMD_STAMP_FLUSH(args_, wave_)                                                                        \
   if ((args_).stamps && (threadIdx.x & 63) == 0) {                                                           \
-    unsigned long long* o_ = (args_).stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (wave_)) * FMD_NSTAMP; \
+    unsigned long long* o_ = (args_).stamps + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (wave_)) * FMD_NSTAMP; \
     for (int k_ = 0; k_ < FMD_NSTAMP; ++k_) o_[k_] = ts_[k_];                                                \
   }
 #define FMD_DBG_SKIP(args_, bit_) (((args_).dbg >> (bit_)) & 1)
@@ -194,6 +194,7 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // compile-time unrolled loop: the body receives std::integral_constant<int, I> (true constants keep
 // every register-array index static, so nothing is demoted to scratch)

@@ -44,8 +44,11 @@ torch.cuda.synchronize()
 lib.fmd_debug_set_stamps(None, -1, 0, 0)
 st = eng.status.tolist()
 tiles_per_wg = (st[2] / args.batch * 1.065 / 32) / (n_wg / args.batch)   # pairs + ~6.5 % pad entries
-t = buf[: n_wg * 8 * NST].view(n_wg, 8, NST).double().cpu()
-for name, sl in (("consumers (waves 0-3)", slice(0, 4)), ("producers (waves 4-7)", slice(4, 8))):
+t = buf.view(n_wg, 16, NST).double().cpu()   # 16 wave slots per workgroup (the forward kernel runs 12 waves)
+groups = [("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8)), ("waves 8-11", slice(8, 12))]
+for name, sl in groups:
+    if t[:, sl].sum() == 0:
+        continue
     m = t[:, sl].mean(dim=(0, 1)) / tiles_per_wg
     print(name, "cycles per tile:", " ".join(f"[{k}]{v:.0f}" for k, v in enumerate(m.tolist())), f" sum {m.sum():.0f}")
 print(f"tiles per workgroup ~{tiles_per_wg:.1f}")
