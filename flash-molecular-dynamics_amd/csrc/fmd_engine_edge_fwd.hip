@@ -6,7 +6,6 @@
 #include "fmd_engine.h"
 
 namespace {
-constexpr int W12_B_AFTER = 2;  // alternating consumers: barrier B after this segment of the update
 // Wave-specialised pair kernels: 8 waves per workgroup, two per SIMD (waves w and w + 4 share one).
 //   waves 0-3 (consumers): own the 32-feature slices -- L1 MFMAs, x1 gathers, aggregate update in LDS
 //   waves 4-7 (producers): rbf values on the VALU, L0 MFMAs, tanh, hidden tile -> LDS
@@ -32,21 +31,15 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 // consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
 // SH: the tile's Gaussians are computed once, by the consumers (consumer w: k-step w) between barriers B and A,
 // and reach the producers as split fragments in LDS (see the backward kernel); used when the region fits.
-// NC = 8 ("alternating consumers", 12 waves, three per SIMD): two consumer waves per feature slice take the workgroup's
-// tiles in turn.  While one runs L1 of its tile on the MFMA pipe the other applies the aggregate update of the tile
-// before (VALU / LDS / gathers): the two updates of a slice never overlap in time -- each sits between two A barriers
-// of a period the other wave spends on L1 -- so the plain read-modify-write of the aggregate stays race free.
-template <int NS0, bool HALF, bool FS, bool SH, int NC = 4>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
-__global__ __launch_bounds__((NC + 4) * 64, NC == 8 ? 3 : 2) void edge_fwd_split_kernel(EdgeArgs a) {
-  static_assert(NC == 4 || (NC == 8 && !FS), "alternating consumers: whole-aggregate mode only");
-  constexpr int NT4 = (NC + 4) * 64 * 4;  // floats one pass of the workgroup covers, four per thread
+template <int NS0, bool HALF, bool FS, bool SH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
+__global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
   float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
   float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
-  const bool producer = wave >= NC;  // wave-uniform
+  const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
   int m, split;
   wg_to_mol_split(m, split);
@@ -54,7 +47,7 @@ __global__ __launch_bounds__((NC + 4) * 64, NC == 8 ? 3 : 2) void edge_fwd_split
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   constexpr int AW = FS ? 64 : F;  // aggregate row width kept in LDS
-  for (int i = tid * 4; i < n * AW; i += NT4) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(agg + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
@@ -257,156 +250,15 @@ __global__ __launch_bounds__((NC + 4) * 64, NC == 8 ? 3 : 2) void edge_fwd_split
           if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
         }
       };
-      if constexpr (NC == 8) {
-        // ---- alternating consumers: wave set X2 owns the workgroup's tiles k = X2, X2 + 2, ... (tile T0 + k S).
-        // Registers (168 per wave at three waves per SIMD): X.oj / X.oi / X.xi of the set's current tile live across its
-        // L1; the neighbour gathers X.xj are issued DURING the update (the j pass does not need them), and the next tile's
-        // offsets are loaded straight into the X.oj registers a segment has finished with -- no second offset set.
-        const int X2 = wave >> 2;
-        // Gaussians: every consumer wave w < NS0 forms HALF a fragment record per tile (set X2: centres 4 X2 .. 4 X2 + 3
-        // of block 2 w + h) in each B-A window, for the tile two periods ahead
-        f32x4 csh;
-        if (SH && w < NS0) csh = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h + 4 * X2);
-        auto share_half = [&]() {
-          if (SH && w < NS0 && 2 * w + h < a.nb) {
-            const float gl = a.gamma * LOG2E;
-            uint32_t xh[2], xl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const f32x2 diff = splat2(d_m) - f32x2{csh[2 * j], csh[2 * j + 1]};
-              split_pair_u(exp2_2((diff * diff) * splat2(gl)), xh[j], xl[j]);
-            }
-            const int blk = 2 * w + h;
-            *reinterpret_cast<u32x2*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4 + 2 * X2) = u32x2{xh[0], xh[1]};
-            *reinterpret_cast<u32x2*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4 + 2 * X2) = u32x2{xl[0], xl[1]};
-          }
-        };
-        if (SH) {
-          fetch_d(T0);
-          share_half();
-          fetch_d(T0 + S);
-          __syncthreads();  // first tile's fragments visible
-          __syncthreads();  // ... and consumed
-          share_half();
-          fetch_d(T0 + 2 * S);
-        }
-        auto meta_load = [&](auto qc, int t_next) {  // raw offsets of segment q of tile t_next
-          constexpr int q = decltype(qc)::value;
-          const int base = min(t_next * 32, last_base);
-          const u32x4 v = *reinterpret_cast<const u32x4*>(poj + base + 8 * q + 4 * h);
-          X.oj[4 * q] = v[0]; X.oj[4 * q + 1] = v[1]; X.oj[4 * q + 2] = v[2]; X.oj[4 * q + 3] = v[3];
-          oi_m[q] = poi[base + 8 * q + 4 * h];
-        };
-        auto begin_tile = [&]() {  // offsets get this lane's column; centre rows requested
-#pragma unroll
-          for (int q = 0; q < 4; ++q) X.oi[q] = oi_m[q] + col4;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) X.oj[r] += col4;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
-        };
-        f32x16 acc1 = zero16();
-        // aggregate update of the set's tile (filter values in acc1), then the offsets of its next tile t_next
-        auto update = [&](int t_next) {
-          float vj[4];
-          auto j_reads = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vj[e] = *reinterpret_cast<const float*>(aggb + X.oj[4 * q + e]);
-          };
-          j_reads(std::integral_constant<int, 0>{});
-          static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              *reinterpret_cast<float*>(aggb + X.oj[4 * q + e]) = vj[e] + X.xi[q] * acc1[4 * q + e];
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (q + 1 < 4) j_reads(std::integral_constant<int, q + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
-            __builtin_amdgcn_sched_barrier(0);
-            meta_load(qc, t_next);
-            __builtin_amdgcn_sched_barrier(0);
-          });
-          FMD_MARK(5)
-          // centre rows: a centre's run may continue in the next segment (either half), so the four read-modify-writes
-          // stay in program order; the sums are formed first
-          float sq[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float si = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) si += X.xj[4 * q + e] * acc1[4 * q + e];
-            sq[q] = fmd_segment_sum(si, X.oi[q]);
-          }
-          static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            const float cval = *reinterpret_cast<const float*>(aggb + X.oi[q]);
-            *reinterpret_cast<float*>(aggb + X.oi[q]) = cval + sq[q];  // both halves store the same value
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        };
-        static_for<0, 4>([&](auto qc) { meta_load(qc, T0 + X2 * S); });
-        begin_tile();
-        __syncthreads();  // A(first)
-        FMD_MARK(11)
-        int k = 0;
-        for (int t = T0; t < ntiles; t += S, ++k) {
-          if ((k & 1) == X2) {
-            // ---------------- own period: L1 of tile t, then the fragments of this set's next tile
-            acc1 = zero16();
-            {
-              const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
-              const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-              f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
-              f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
-              static_for<0, 8>([&](auto sc) {
-                constexpr int s = decltype(sc)::value;
-                f16x8 ahn = ah1, aln = al1;
-                if constexpr (s + 2 < 8) {
-                  ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
-                  aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
-                }
-                FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
-                ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
-                __builtin_amdgcn_sched_barrier(0);
-              });
-            }
-            FMD_MARK(0)
-            asm volatile("" : "+v"(acc1));  // L1 (and its LDS reads) complete before the barrier
-            FMD_MARK(1)
-            __syncthreads();  // B(t)
-            FMD_MARK(2)
-            share_half();   // tile t + 2 S
-            fetch_d(t + 3 * S);
-            FMD_MARK(3)
-            __syncthreads();  // A(t+S)
-            FMD_MARK(4)
-          } else {
-            // ---------------- the other set's period: update of this set's tile t - S (its L1 ran one period ago)
-            if (k > 0) update(t + S);  // wave-uniform
-            FMD_MARK(6)
-            __syncthreads();  // B(t)
-            share_half();
-            fetch_d(t + 3 * S);
-            if (k > 0) begin_tile();
-            FMD_MARK(7)
-            __syncthreads();  // A(t+S)
-            FMD_MARK(8)
-          }
-        }
-        if (((k - 1) & 1) == X2) update(0);  // the last tile (the other set finished before the last A)
-      } else {
       if (SH) {
-          fetch_d(T0);
-          share_fragments();
-          fetch_d(T0 + S);
-          __syncthreads();  // first tile's fragments visible
-          __syncthreads();  // ... and consumed
-          share_fragments();
-          fetch_d(T0 + 2 * S);
-        }
+        fetch_d(T0);
+        share_fragments();
+        fetch_d(T0 + S);
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+        fetch_d(T0 + 2 * S);
+      }
       fetch_meta(T0);
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
       f32x16 fl_prev = zero16();
@@ -497,7 +349,6 @@ __global__ __launch_bounds__((NC + 4) * 64, NC == 8 ? 3 : 2) void edge_fwd_split
         FMD_MARK(5)
       }
       message(fl_prev);  // last tile
-      }  // NC == 4
       }
     }
   }
@@ -505,13 +356,13 @@ __global__ __launch_bounds__((NC + 4) * 64, NC == 8 ? 3 : 2) void edge_fwd_split
   __syncthreads();
   float* out = a.slabs + split * a.slab_stride + a0 * F;
   if (FS) {  // this half's 64 features, zeros in the other half (the node kernels add the slabs)
-    for (int i = tid * 4; i < n * 64; i += NT4) {
+    for (int i = tid * 4; i < n * 64; i += 2048) {
       const int row = i >> 6, c = i & 63;
       *reinterpret_cast<f32x4*>(out + row * F + 64 * split + c) = *reinterpret_cast<const f32x4*>(agg + i);
       *reinterpret_cast<f32x4*>(out + row * F + 64 * (1 - split) + c) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   } else {
-    for (int i = tid * 4; i < n * F; i += NT4)
+    for (int i = tid * 4; i < n * F; i += 2048)
       *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
   }
 }
@@ -526,9 +377,7 @@ int setup_edge_fwd_attrs() {
                        (const void*)edge_fwd_split_kernel<2, false, false, true>,
                        (const void*)edge_fwd_split_kernel<4, false, false, false>, (const void*)edge_fwd_split_kernel<4, true, false, false>,
                        (const void*)edge_fwd_split_kernel<4, false, true, false>,  (const void*)edge_fwd_split_kernel<4, true, true, false>,
-                       (const void*)edge_fwd_split_kernel<4, false, false, true>,
-                       (const void*)edge_fwd_split_kernel<2, false, false, true, 8>, (const void*)edge_fwd_split_kernel<4, false, false, true, 8>,
-                       (const void*)edge_fwd_split_kernel<2, true, false, false, 8>, (const void*)edge_fwd_split_kernel<4, true, false, false, 8>};
+                       (const void*)edge_fwd_split_kernel<4, false, false, true>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)
       return FMD_ELAUNCH;
@@ -547,8 +396,8 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
   if (a.fs && half) edge_fwd_split_kernel<NS0, true, true, false><<<grid, 512, lds, s>>>(a);
   else if (a.fs) edge_fwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(a);
-  else if (sh) edge_fwd_split_kernel<NS0, false, false, true, 8><<<grid, 768, lds_sh, s>>>(a);
-  else if (half) edge_fwd_split_kernel<NS0, true, false, false, 8><<<grid, 768, lds, s>>>(a);
+  else if (sh) edge_fwd_split_kernel<NS0, false, false, true><<<grid, 512, lds_sh, s>>>(a);
+  else if (half) edge_fwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(a);
   else edge_fwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(a);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
