@@ -5,7 +5,8 @@
 
 namespace {
 // ---------------------------------------------------------------------------------------------
-// pair list: undirected i<j, strict d2 < rc2 with unfused fp32, sorted by centre i then j.
+// pair list: undirected pairs, strict d2 < rc2 with unfused fp32, each listed once under ONE of its two beads (the
+// "centre": the smaller index unless the orientation step below moved the pair), sorted by centre then neighbour.
 // Each centre's entries are padded to a multiple of 4 (pad = (i,i) with d = rc, whose cutoff is 0), so a
 // 4-entry half of an 8-entry SEGMENT of a 32-entry tile always belongs to one centre, and both halves do
 // unless the rows are disjoint (see the conflict flags below): inside a segment the neighbours j are
@@ -88,9 +89,42 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     }
   }
   __syncthreads();
+  // ---- orientation: an undirected pair may sit in either endpoint's run (the edge kernels update both rows of an
+  //      entry, finish_kernel takes the direction from the positions), so a row whose run is r = cnt mod 4 entries past a
+  //      multiple of four GIVES r of its pairs (i, j) to the rows j: they become (j, i), and the run needs no pad
+  //      entries.  A decision needs the final count of its row, so the rows are taken in a few blocks (each half of
+  //      what remains) and a row gives only to rows of LATER blocks -- its largest neighbours -- which makes the rows
+  //      of one block independent: 5.7 % pad entries -> 0.4 % at the bench size (7 barriers).
+  for (int lo_b = 0; n - lo_b > 8;) {  // uniform over the workgroup
+    const int hi_b = lo_b + max(4, (n - lo_b) >> 1);
+    const int i = lo_b + tid;
+    if (i < hi_b) {
+      int c_i = cnt[i], give = c_i & 3;
+      for (int c = NC - 1; c >= (hi_b >> 6) && give > 0; --c) {
+        const unsigned long long orig = masks[i * NC + c];
+        unsigned long long m2 = orig;
+        if (c == (hi_b >> 6)) m2 &= ~0ull << (hi_b & 63);  // neighbours in later blocks only (all of them are > i)
+        while (m2 && give > 0) {
+          const int bt = 63 - __clzll((long long)m2);
+          m2 ^= 1ull << bt;
+          const int j = 64 * c + bt;
+          atomicOr(&masks[j * NC + (i >> 6)], 1ull << (i & 63));
+          atomicAdd(&cnt[j], 1);
+          --give;
+          --c_i;
+        }
+        const unsigned long long keep = (c == (hi_b >> 6)) ? (m2 | (orig & ~(~0ull << (hi_b & 63)))) : m2;
+        masks[i * NC + c] = keep;
+      }
+      cnt[i] = c_i;
+    }
+    __syncthreads();
+    lo_b = hi_b;
+  }
   // ---- which rows may share an 8-entry segment with the row before them: the two halves of a segment are
   //      updated side by side, so the centre and the (at most four) first neighbours of row i must not appear among
-  //      the neighbours in the last group of four of the row before (centres ascend, so they cannot meet otherwise)
+  //      the neighbours in the last group of four of the row before, nor the centre of the row before among those
+  //      first neighbours (a pair it gave away)
   for (int i = tid; i < n; i += 1024) {
     bool cf = false;
     if (cnt[i] > 0) {
@@ -100,7 +134,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
         // the row's first (at most four) neighbours and the last rp of the row before, as 16-bit fields
         unsigned long long hd = ~0ull, tl = ~0ull;
         int hn = 0, tn = 0;
-        for (int c = (i + 1) >> 6; c < NC && hn < 4; ++c) {
+        for (int c = 0; c < NC && hn < 4; ++c) {
           unsigned long long m2 = masks[i * NC + c];
           while (m2 && hn < 4) {
             hd = (hd << 16) | (unsigned long long)(64 * c + __ffsll((long long)m2) - 1);
@@ -109,7 +143,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
           }
         }
         const int rp = ((cnt[p] - 1) & 3) + 1;
-        for (int c = NC - 1; c >= ((p + 1) >> 6) && tn < rp; --c) {
+        for (int c = NC - 1; c >= 0 && tn < rp; --c) {
           unsigned long long m2 = masks[p * NC + c];
           while (m2 && tn < rp) {
             const int bt = 63 - __clzll((long long)m2);
@@ -125,6 +159,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
 #pragma unroll
           for (int y = 0; y < 4; ++y) hit |= tv == ((unsigned)(hd >> (16 * y)) & 0xffffu);
           cf |= tv != 0xffffu && hit;
+          cf |= ((unsigned)(hd >> (16 * t)) & 0xffffu) == (unsigned)p;  // a pair the row before gave to this one
         }
       }
     }
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     const unsigned rlo = (unsigned)mrow, rhi = (unsigned)(mrow >> 32);
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      if (c >= ((i + 1) >> 6) && c < NC) {
+      if (c < NC) {
         const unsigned lo = __builtin_amdgcn_readlane(rlo, c), hi = __builtin_amdgcn_readlane(rhi, c);
         const unsigned long long mk = ((unsigned long long)hi << 32) | lo;  // wave-uniform: used as the execution mask
         if (__builtin_amdgcn_inverse_ballot_w64(mk)) {
