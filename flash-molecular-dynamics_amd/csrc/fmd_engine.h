@@ -61,7 +61,13 @@ constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // split operand, K padded to 64: [w
 constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
 constexpr int SLICE = 2 * Q1_FLOATS;        // floats of one packed 128x128 node operand: hi record, lo record
 
+// A pair-kernel workgroup walks up to two WORK ITEMS (sched_body writes them once per force evaluation): item =
+// ITEM_INTS ints {molecule (-1: none), first tile, end tile, tile stride, row of the slab buffer that takes the item's
+// aggregate, 0, 0, 0}; workgroup (molecule m, split s) reads items[(m * n_split + s) * 2 + 0 / 1].
+constexpr int ITEM_INTS = 8;
+
 struct EdgeArgs {
+  const int* items;        // [n_mol * n_split][2][ITEM_INTS]
   const uint32_t* poi;     // centre row byte offsets (i * 512)
   const uint32_t* poj;     // neighbour row byte offsets (j * 512)
   const float* pd;
@@ -80,7 +86,7 @@ struct EdgeArgs {
   float c0;                                          // cutoff / 2
   int nb;                                            // ceil(num_rbf / 8): half k-steps that hold Gaussians
   const float* centers;    // [64]
-  float* slabs;            // [n_split][N,128] partial aggregates (fwd: agg, bwd: gx1)
+  float* slabs;            // [n_split + 1][N,128] partial aggregates (fwd: agg, bwd: gx1); the last: extra pieces
   int64_t slab_stride;
   float gamma, rc;
   int cap, n_split;
@@ -97,6 +103,7 @@ struct NodeFwdArgs {
   const float* slabs;  // agg partials of the previous block
   int64_t slab_stride;
   int n_slabs;
+  const int* extra_row;  // [N] row of the slab buffer that holds one more partial of this row, or -1
   const float *l2, *b2, *l3, *b3;  // previous block's lin2 / lin
   float* t_out;        // tanh(conv) of the previous block (kept for backward)
   const float* l1;     // this block's lin1
@@ -109,6 +116,7 @@ struct NodeOutArgs {
   const float* slabs;
   int64_t slab_stride;
   int n_slabs;
+  const int* extra_row;
   const float *l2, *b2, *l3, *b3;
   float* t_out;
   const float* po[3];   // packed output linears
@@ -124,6 +132,7 @@ struct NodeBwdArgs {
   const float* slabs;    // gx1 partials of block l+1
   int64_t slab_stride;
   int n_slabs;
+  const int* extra_row;
   const float* l1t;      // lin1 of block l+1, transposed operand
   const float* t;        // tanh(conv) of block l
   const float *l3t, *l2t;
@@ -143,6 +152,17 @@ struct PairsArgs {
   int32_t* report;         // [n_mol][3] pairs_kernel -> finish_kernel
   int max_beads;
   float* forces;           // zeroed here, accumulated by finish
+  int* extra_row;          // [N] set to -1 here (sched_body names the rows that have an extra partial)
+};
+struct SchedArgs {
+  const int32_t* npairs;
+  const int64_t* mol_ptr;
+  int n_mol, n_split;
+  int balanced;            // 1: even out the tiles over the workgroups (one wave of workgroups, n_mol <= 256)
+  int fs;
+  int64_t n_nodes;
+  int* items;
+  int* extra_row;
 };
 struct FinishArgs {
   const float* pos;
@@ -171,7 +191,7 @@ int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s);
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s);
 int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol, hipStream_t s);
 int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x1, float* x, float* x1,
-                      int64_t n_nodes, hipStream_t s);
+                      int64_t n_nodes, const SchedArgs& sa, hipStream_t s);
 int launch_node_fwd(const NodeFwdArgs& a, unsigned grid, hipStream_t s);
 int launch_node_out(const NodeOutArgs& a, int num_out, bool hout, unsigned grid, hipStream_t s);
 int launch_node_bwd(const NodeBwdArgs& a, bool has_slabs, unsigned grid, hipStream_t s);

@@ -63,8 +63,14 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
-  int m, split;
-  wg_to_mol_split(m, split);
+  int m_own, split;
+  wg_to_mol_split(m_own, split);
+  const int* wi = a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);  // work items: see the forward kernel
+  FMD_STAMP_DECL
+  for (int it = 0; it < 2; ++it) {
+  const int m = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it]);
+  if (m < 0) break;
+  if (it) __syncthreads();  // the flush of the item before has read the aggregate
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -79,16 +85,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const float* pcut = a.pc + (int64_t)m * a.cap;
   const float* pdcut = a.pdc + (int64_t)m * a.cap;
   float* pgd = a.pgd + (int64_t)m * a.cap + (FS ? split * a.pgd_stride : 0);  // FS: one dE/dd slab per half
-  const int ntiles = (np + 31) >> 5;
-  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
-  const int T0 = FS ? 0 : split;     // its first tile
+  const int ntiles = (np + 31) >> 5;  // of the molecule
+  const int T0 = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 1]);
+  const int t_end = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 2]);
+  const int S = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 3]);
+  const int dst_row = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 4]);
   const int last_base = (ntiles - 1) * 32;
-  FMD_STAMP_DECL
   const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
   (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
-  if (T0 < ntiles) {  // uniform over the workgroup
+  if (T0 < t_end) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       put();
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < ntiles; t += S) {
+      for (int t = T0; t < t_end; t += S) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
         __syncthreads();     // B(t)
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       form_gw();  // first tile
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < ntiles; t += S) {
+      for (int t = T0; t < t_end; t += S) {
         fetch_d(t + 2 * S);  // for the fragments written after C(t)
         if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
           __syncthreads();  // B(t)
@@ -499,10 +506,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       }
     }
   }
-  FMD_STAMP_FLUSH(a, wave)
   if (NEED_GX1) {
     __syncthreads();
-    float* out = a.slabs + split * a.slab_stride + a0 * F;
+    float* out = a.slabs + (int64_t)dst_row * F;
     if (FS) {  // this half's 64 features, zeros in the other half
       for (int i = tid * 4; i < n * 64; i += 2048) {
         const int row = i >> 6, c = i & 63;
@@ -514,6 +520,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(gx1 + i);
     }
   }
+  (void)dst_row;
+  }  // work items
+  FMD_STAMP_FLUSH(a, wave)
 }
 
 }  // namespace

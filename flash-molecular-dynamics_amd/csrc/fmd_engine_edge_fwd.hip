@@ -41,8 +41,15 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
-  int m, split;
-  wg_to_mol_split(m, split);
+  int m_own, split;
+  wg_to_mol_split(m_own, split);
+  // this workgroup's work items (sched_body): runs of tiles of one molecule, each with its own aggregate and slab
+  const int* wi = a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);
+  FMD_STAMP_DECL
+  for (int it = 0; it < 2; ++it) {
+  const int m = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it]);
+  if (m < 0) break;
+  if (it) __syncthreads();  // the flush of the item before has read the aggregate
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -52,16 +59,17 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
   const float* pdist = a.pd + (int64_t)m * a.cap;
   const float* pcut = a.pc + (int64_t)m * a.cap;
-  const int ntiles = (np + 31) >> 5;
-  const int S = FS ? 1 : a.n_split;  // tile stride of this workgroup
-  const int T0 = FS ? 0 : split;     // its first tile
+  const int ntiles = (np + 31) >> 5;  // of the molecule: prefetches past the item's end stay inside its list
+  const int T0 = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 1]);     // the item's first tile,
+  const int t_end = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 2]);  // end,
+  const int S = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 3]);      // tile stride
+  const int dst_row = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 4]);
   const int last_base = (ntiles - 1) * 32;
-  FMD_STAMP_DECL
   const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
   (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
-  if (T0 < ntiles) {  // uniform over the workgroup
+  if (T0 < t_end) {  // uniform over the workgroup
     if (producer) {
       // ------------------------------------------------------------------ producer waves
       f16x8 a0h[NS0], a0l[NS0];
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       put();
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < ntiles; t += S) {
+      for (int t = T0; t < t_end; t += S) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
         FMD_MARK(0)
         __syncthreads();     // B(t)
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       // ------------------------------------------------------------------ consumer waves
       if (FS && w >= 2) {  // no feature slice for this wave in FS mode: keep the barrier protocol
         __syncthreads();  // A(first)
-        for (int t = T0; t < ntiles; t += S) {
+        for (int t = T0; t < t_end; t += S) {
           __syncthreads();  // B(t)
           __syncthreads();  // A(t+S)
         }
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       f32x16 fl_prev = zero16();
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < ntiles; t += S) {
+      for (int t = T0; t < t_end; t += S) {
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
         {
@@ -352,9 +360,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       }
     }
   }
-  FMD_STAMP_FLUSH(a, wave)
   __syncthreads();
-  float* out = a.slabs + split * a.slab_stride + a0 * F;
+  float* out = a.slabs + (int64_t)dst_row * F;
   if (FS) {  // this half's 64 features, zeros in the other half (the node kernels add the slabs)
     for (int i = tid * 4; i < n * 64; i += 2048) {
       const int row = i >> 6, c = i & 63;
@@ -365,6 +372,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
     for (int i = tid * 4; i < n * F; i += 2048)
       *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
   }
+  }  // work items
+  FMD_STAMP_FLUSH(a, wave)
 }
 
 }  // namespace

@@ -97,6 +97,8 @@ struct Workspace {
   uint32_t *poi, *poj;
   int32_t* npairs;
   int32_t* report;  // [n_mol][3] pairs_kernel -> finish_kernel
+  int* items;       // [n_mol * n_split][2][ITEM_INTS] work items of the pair kernels (sched_body)
+  int* extra_row;   // [N]
   int64_t total;
 };
 
@@ -136,7 +138,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
     w.x1[l] = (float*)take(nf);
     w.t[l] = (float*)take(nf);
   }
-  w.slabs = (float*)take(nf * n_split);
+  w.slabs = (float*)take(nf * (n_split + 1));  // the last one: extra pieces of the balanced schedule (at most N rows)
   w.e_node = (float*)take(n_nodes * 4);
   w.poi = (uint32_t*)take(n_mol * cap * 4);
   w.poj = (uint32_t*)take(n_mol * cap * 4);
@@ -146,6 +148,8 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   w.pgd = (float*)take(2 * n_mol * cap * 4);  // second slab: feature-split mode
   w.npairs = (int32_t*)take(n_mol * 4);
   w.report = (int32_t*)take(n_mol * 12);
+  w.items = (int*)take(n_mol * n_split * 2 * ITEM_INTS * 4);
+  w.extra_row = (int*)take(n_nodes * 4);
   w.total = p - reinterpret_cast<char*>(base);
   return w;
 }
@@ -289,6 +293,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
   const int split = fs ? 2 : resolve_split(desc, n_mol);  // FS: the two feature halves
+  if ((int64_t)(split + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
   const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, split);
   const PackLayout PL = pack_layout(desc);
   const float* pk = reinterpret_cast<const float*>(packed_dev);
@@ -300,11 +305,17 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   // a NULL slot skips that record: a caller may time a single kernel without paying for 2 records per launch
   auto ev_begin = [&]() { if (ev && ev[2 * kidx]) (void)hipEventRecord(ev[2 * kidx], s); };
   auto ev_end = [&]() { if (ev && ev[2 * kidx + 1]) (void)hipEventRecord(ev[2 * kidx + 1], s); ++kidx; };
+  SchedArgs sa;
   {
     PairsArgs pa;
     pa.pos = pos; pa.mol_ptr = mol_ptr; pa.rc = desc->cutoff; pa.cap = (int)cap; pa.poi = ws.poi; pa.poj = ws.poj;
     pa.pd = ws.pd; pa.pc = ws.pc; pa.pdc = ws.pdc; pa.npairs = ws.npairs; pa.report = ws.report;
-    pa.max_beads = (int)max_beads_per_mol; pa.forces = forces;
+    pa.max_beads = (int)max_beads_per_mol; pa.forces = forces; pa.extra_row = ws.extra_row;
+    // the pair kernels' work items (sched_body in fmd_engine_pairs.hip): balanced when the split is left to the library
+    // and the whole launch is one round of workgroups; a caller-given n_split keeps the static tile interleave
+    sa.npairs = ws.npairs; sa.mol_ptr = mol_ptr; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
+    sa.balanced = (!fs && n_mol >= 2 && n_mol <= 256 && n_mol * split <= device_cus() && desc->n_split == 0) ? 1 : 0;
+    sa.n_nodes = n_nodes; sa.items = ws.items; sa.extra_row = ws.extra_row;
     ev_begin();
     rc = launch_pairs(pa, n_mol, s);
     ev_end();
@@ -321,6 +332,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   auto edge = [&](bool fwd, int l) -> int {
     const BlockOff o = block_off(PL, l);
     EdgeArgs ea;
+    ea.items = ws.items;
     ea.poi = ws.poi; ea.poj = ws.poj; ea.pd = ws.pd; ea.pc = ws.pc; ea.pdc = ws.pdc; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
     ea.mol_ptr = mol_ptr; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
     ea.b0 = pk + o.b0;
@@ -343,11 +355,11 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     const BlockOff o = block_off(PL, l);
     ev_begin();
     if (l == 0) {
-      rc = launch_node_embed(atom_types, pk + PL.emb, pk + PL.emb_x1, ws.x, ws.x1[0], n_nodes, s);
+      rc = launch_node_embed(atom_types, pk + PL.emb, pk + PL.emb_x1, ws.x, ws.x1[0], n_nodes, sa, s);
     } else {
       const BlockOff q = block_off(PL, l - 1);
       NodeFwdArgs na;
-      na.x = ws.x; na.slabs = ws.slabs; na.slab_stride = slab_stride; na.n_slabs = split;
+      na.x = ws.x; na.slabs = ws.slabs; na.slab_stride = slab_stride; na.n_slabs = split; na.extra_row = ws.extra_row;
       na.l1 = pk + o.l1; na.x1_out = ws.x1[l]; na.n_nodes = n_nodes;
       na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
       rc = launch_node_fwd(na, res_grid, s);
@@ -362,7 +374,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   {
     const BlockOff q = block_off(PL, L - 1);
     NodeOutArgs oa;
-    oa.x = ws.x; oa.slabs = ws.slabs; oa.slab_stride = slab_stride; oa.n_slabs = split;
+    oa.x = ws.x; oa.slabs = ws.slabs; oa.slab_stride = slab_stride; oa.n_slabs = split; oa.extra_row = ws.extra_row;
     oa.l2 = pk + q.l2; oa.b2 = pk + q.b2; oa.l3 = pk + q.l3; oa.b3 = pk + q.b3; oa.t_out = ws.t[L - 1];
     for (int k = 0; k < 3; ++k) {
       const int kk = k < desc->num_out ? k : desc->num_out - 1;
@@ -379,7 +391,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   for (int l = L - 1; l >= 0; --l) {
     const BlockOff o = block_off(PL, l);
     NodeBwdArgs ba;
-    ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = split;
+    ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = split; ba.extra_row = ws.extra_row;
     ba.t = ws.t[l]; ba.l3t = pk + o.l3t; ba.l2t = pk + o.l2t; ba.gagg = ws.gagg; ba.n_nodes = n_nodes;
     ba.l1t = l == L - 1 ? nullptr : pk + block_off(PL, l + 1).l1t;
     ev_begin();

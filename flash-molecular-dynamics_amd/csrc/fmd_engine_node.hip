@@ -4,23 +4,6 @@
 #include "fmd_engine.h"
 
 namespace {
-// first node launch of a timestep: x = embedding[type], x1 = (embedding lin1^T)[type] from the packed table
-// (32 lanes x 16 bytes per bead and array)
-__global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restrict__ types,
-                                                         const float* __restrict__ emb,
-                                                         const float* __restrict__ emb_x1,
-                                                         float* __restrict__ x, float* __restrict__ x1,
-                                                         int64_t n_nodes) {
-  const int64_t total = n_nodes * 32, stride = (int64_t)gridDim.x * 256;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
-    const int64_t n = idx >> 5;
-    const int c = (int)(idx & 31) * 4;
-    const int64_t ty = types[n];
-    *reinterpret_cast<f32x4*>(x + n * F + c) = *reinterpret_cast<const f32x4*>(emb + ty * F + c);
-    *reinterpret_cast<f32x4*>(x1 + n * F + c) = *reinterpret_cast<const f32x4*>(emb_x1 + ty * F + c);
-  }
-}
-
 // ---- register-resident, transposed-product forms of node_fwd / node_bwd (split-operand engines).
 // The streamed 32-row chains above are bound by latency and by VALU work around the GEMMs, not by the matrix
 // pipe: every stage waits for its operand fragments from L2 and every tile for its rows from HBM; every output
@@ -39,10 +22,13 @@ constexpr int NLD = 144;              // halves per row of an activation plane (
 constexpr int NPLANE = 32 * NLD;      // halves of one plane; a tile is the hi plane followed by the lo plane
 struct RowsPre {
   f32x4 s0[4], s1[4];
+  int er;  // row of the slab buffer with one more partial of this thread's row (sched_body), or -1
 };
 __device__ __forceinline__ void rows_fetch(RowsPre& p, const float* __restrict__ src, int64_t slab_stride,
-                                           int n_slabs, int64_t row0, int64_t n_rows, int tid) {
+                                           int n_slabs, const int* __restrict__ extra_row, int64_t row0,
+                                           int64_t n_rows, int tid) {
   const int r = tid >> 3, c0 = (tid & 7) * 4;
+  p.er = (extra_row && row0 + r < n_rows) ? extra_row[row0 + r] : -1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     p.s0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -63,9 +49,11 @@ __device__ __forceinline__ void planes_store4(_Float16* tile, int r, int c, cons
 }
 // same summation order as rows_to_lds: ((s0 + s1) + s2) + ...
 __device__ __forceinline__ void rows_commit(_Float16* tile, const RowsPre& p, const float* __restrict__ src,
-                                            int64_t slab_stride, int n_slabs, int64_t row0, int64_t n_rows,
-                                            int tid) {
+                                            int64_t slab_stride, int n_slabs, const int* __restrict__ extra_row,
+                                            int64_t row0, int64_t n_rows, int tid) {
   const int r = tid >> 3, c0 = (tid & 7) * 4;
+  // a molecule whose tiles were spread over one more workgroup (sched_body) has one more partial per row
+  const int er = extra_row ? p.er : -1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + 32 * i;
@@ -75,6 +63,7 @@ __device__ __forceinline__ void rows_commit(_Float16* tile, const RowsPre& p, co
       const float* q = src + (row0 + r) * F + c;
       for (int s = 2; s < n_slabs; ++s) v += *reinterpret_cast<const f32x4*>(q + s * slab_stride);
     }
+    if (er >= 0) v += *reinterpret_cast<const f32x4*>(src + (int64_t)er * F + c);
     planes_store4(tile, r, c, v);
   }
 }
@@ -131,7 +120,7 @@ __global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
   if (tile >= n_tiles) return;
   BFrag w1, w2, w3;
   RowsPre pre;
-  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
   f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
   load_bfrag(w2, a.l2, w, lane);
   load_bfrag(w3, a.l3, w, lane);
@@ -140,10 +129,10 @@ __global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
     const bool ok = row < a.n_nodes;
-    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     const f32x16 x_old = xo;
     if (next < n_tiles) {
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, next * 32, a.n_nodes, tid);
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
       xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
     }
     __syncthreads();
@@ -187,9 +176,9 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
     t_nx = load_cols(a.t, row, row < a.n_nodes, w, h);
     if (HAS_SLABS) {
       gx_nx = load_cols(a.gx, row, row < a.n_nodes, w, h);
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, t * 32, a.n_nodes, tid);
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, t * 32, a.n_nodes, tid);
     } else {
-      rows_fetch(pre, a.gx, 0, 1, t * 32, a.n_nodes, tid);
+      rows_fetch(pre, a.gx, 0, 1, nullptr, t * 32, a.n_nodes, tid);
     }
   };
   fetch(tile);
@@ -203,9 +192,9 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
     f32x16 gx_pre;
     if (HAS_SLABS) {
       gx_pre = gx_nx;
-      rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+      rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     } else {
-      rows_commit(bufY, pre, a.gx, 0, 1, tile * 32, a.n_nodes, tid);
+      rows_commit(bufY, pre, a.gx, 0, 1, nullptr, tile * 32, a.n_nodes, tid);
     }
     if (next < n_tiles) fetch(next);
     f32x16 acc;
@@ -289,7 +278,7 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     else cols_to_planes(t, v, w, lane);
   };
   RowsPre pre;
-  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
   f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
   load_bfrag(fb0, ops[0], w, lane);
   const f32x16 b2 = load_cols(a.b2, 0, true, w, h), b3 = load_cols(a.b3, 0, true, w, h);
@@ -297,10 +286,10 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
     const bool ok = row < a.n_nodes, more = next < n_tiles;
-    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, tile * 32, a.n_nodes, tid);
+    rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     const f32x16 x_old = xo;
     if (more) {
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, next * 32, a.n_nodes, tid);
+      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
       xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
     }
     __syncthreads();
@@ -364,12 +353,6 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
 
 namespace fmd_eng {
 
-int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x1, float* x, float* x1,
-                      int64_t n_nodes, hipStream_t s) {
-  const int64_t want = (n_nodes * 32 + 255) / 256;
-  node_embed_kernel<<<(unsigned)(want < 4096 ? want : 4096), 256, 0, s>>>(types, emb, emb_x1, x, x1, n_nodes);
-  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
-}
 int launch_node_fwd(const NodeFwdArgs& a, unsigned grid, hipStream_t s) {
   node_fwd_res_kernel<<<grid, 256, 0, s>>>(a);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
-                                                    int32_t* __restrict__ report, int max_beads, float* __restrict__ forces, int ent_cap) {
+                                                    int32_t* __restrict__ report, int max_beads, float* __restrict__ forces, int ent_cap,
+                                                    int* __restrict__ extra_row) {
   // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
   // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
   // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
@@ -49,8 +50,10 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     sz[i] = pos[3 * (a0 + i) + 2];
   }
   // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
-  if (part == 0)
+  if (part == 0) {
     for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
+    for (int i = tid; i < (int)(mol_ptr[m + 1] - a0); i += 1024) extra_row[a0 + i] = -1;  // sched_body names the exceptions
+  }
   __syncthreads();
   auto dist2 = [&](int i, int j) {
     const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
@@ -340,6 +343,141 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work items of the pair kernels (fmd_engine.h ITEM_INTS): one workgroup of 256 threads, once per force evaluation
+// (the first workgroup of node_embed_kernel, beside the embedding lookup: no launch of its own).
+// A pair-kernel workgroup keeps ONE molecule's aggregate in LDS, so a molecule's tiles can only be shared among
+// workgroups that each pay for an aggregate (and a slab in HBM).  Static form (balanced = 0): workgroup (m, s) walks
+// the tiles s, s + S, ... of molecule m.  When all workgroups fit the chip at once (one per CU), the launch lasts as
+// long as its LARGEST molecule needs -- 11 % above the mean at the bench size -- so the balanced form caps every run
+// at q tiles: workgroup (m, s) takes tiles [s q, (s + 1) q) of m, and what a large molecule has beyond S q goes, as a
+// second item with its own (extra) slab, to the last workgroup of a small molecule: the k-th largest is paired with
+// the k-th smallest.  q is the smallest cap for which every such pair fits into q tiles.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sched_body(const SchedArgs& a) {
+  __shared__ int key[256];    // tiles * 256 + molecule, sorted descending
+  __shared__ int xoff[256];   // first row of a large molecule's extra slab
+  __shared__ int tot_s;
+  const int tid = threadIdx.x, S = a.n_split, B = a.n_mol, N = (int)a.n_nodes;
+  auto put = [&](int64_t w, int slot, int mol, int tb, int te, int stride, int dst) {
+    int4* o = reinterpret_cast<int4*>(a.items + (w * 2 + slot) * ITEM_INTS);
+    o[0] = int4{mol, tb, te, stride};
+    o[1] = int4{dst, 0, 0, 0};
+  };
+  if (!a.balanced) {
+    for (int64_t w = tid; w < (int64_t)B * S; w += 256) {
+      const int m = (int)(w / S), s = (int)(w % S);
+      const int nt = (a.npairs[m] + 31) >> 5, a0 = (int)a.mol_ptr[m];
+      if (a.fs) put(w, 0, m, 0, nt, 1, s * N + a0);  // feature split: both workgroups walk all tiles
+      else put(w, 0, m, s, nt, S, s * N + a0);
+      put(w, 1, -1, 0, 0, 1, 0);
+    }
+    return;
+  }
+  // (all global reads up front, one round trip: the lookup's traffic runs beside this workgroup)
+  const int t_me = tid < B ? (a.npairs[tid] + 31) >> 5 : 0;
+  const int a0_me = tid < B ? (int)a.mol_ptr[tid] : 0, n_me = tid < B ? (int)(a.mol_ptr[tid + 1] - a.mol_ptr[tid]) : 0;
+  __shared__ int a0_m[256], n_m[256];
+  a0_m[tid] = a0_me;
+  n_m[tid] = n_me;
+  __shared__ __attribute__((aligned(16))) int raw[256];
+  const int my = tid < B ? t_me * 256 + tid : -1;
+  raw[tid] = my;
+  if (tid == 0) tot_s = 0;
+  __syncthreads();
+  // rank sort, descending (the keys are distinct: every thread counts the keys above its own; broadcast LDS reads)
+  int rank = 0;
+#pragma unroll 8
+  for (int k = 0; k < ((B + 3) & ~3); k += 4) {  // (unused slots hold -1: never above a key)
+    const int4 v = *reinterpret_cast<const int4*>(raw + k);
+    rank += (v.x > my ? 1 : 0) + (v.y > my ? 1 : 0) + (v.z > my ? 1 : 0) + (v.w > my ? 1 : 0);
+  }
+  key[tid < B ? rank : tid] = my;  // (my = -1 beyond the batch)
+  {
+    int tw = t_me;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tw += __shfl_xor(tw, o, 64);
+    if ((tid & 63) == 0) atomicAdd(&tot_s, tw);
+  }
+  __syncthreads();
+  const int tk = tid < B ? key[tid] >> 8 : 0;  // tiles of the tid-th largest molecule
+  const int mk = tid < B ? key[tid] & 255 : 0;  // ... which is molecule mk: rows [a0k, a0k + nk)
+  const int a0k = tid < B ? a0_m[mk] : 0, nk = tid < B ? n_m[mk] : 0;
+  // the cap q.  A molecule that is large at a cap (tk > S q) objects to it while its partner, the tid-th smallest, is
+  // large as well or the two do not fit into the partner's last workgroup; both conditions relax as q grows, so every
+  // thread finds the first cap it accepts by bisection (at q = ceil(tk / S) it is not large any more) and the
+  // largest of those wins.
+  const int q0 = max(1, (tot_s + S * B - 1) / (S * B));
+  const int tp = tid < B ? key[B - 1 - tid] >> 8 : 0;
+  auto objects = [&](int qc) {
+    return tk > S * qc && (tp > S * qc || (tk - S * qc) + max(0, tp - (S - 1) * qc) > qc);
+  };
+  int qk = q0;
+  if (tid < B && objects(q0)) {
+    int lo = q0, hi = max(q0, (tk + S - 1) / S);  // objects at lo, accepts hi
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (objects(mid)) lo = mid; else hi = mid;
+    }
+    qk = hi;
+  }
+  __shared__ int qmax_s[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qk = max(qk, __shfl_xor(qk, o, 64));
+  if ((tid & 63) == 0) qmax_s[tid >> 6] = qk;
+  __syncthreads();
+  const int q = max(max(qmax_s[0], qmax_s[1]), max(qmax_s[2], qmax_s[3]));
+  const int n_large = __syncthreads_count(tid < B && tk > S * q);
+  // rows of the extra slabs: exclusive prefix sum of the large molecules' bead counts (one wave-free LDS pass)
+  __shared__ int nb_s[256], a0_s[256];
+  nb_s[tid] = nk;
+  a0_s[tid] = a0k;
+  __syncthreads();
+  if (tid == 0) {
+    int off = 0;
+    for (int k = 0; k < n_large; ++k) {
+      xoff[k] = off;
+      off += nb_s[k];
+    }
+  }
+  if (tid < B) {
+    for (int s = 0; s < S; ++s) {  // an empty run still zeroes and writes its slab
+      put((int64_t)mk * S + s, 0, mk, min(s * q, tk), min((s + 1) * q, tk), 1, s * N + a0k);
+      put((int64_t)mk * S + s, 1, -1, 0, 0, 1, 0);
+    }
+  }
+  __syncthreads();
+  if (tid < n_large) {
+    const int mp = key[B - 1 - tid] & 255;
+    put((int64_t)mp * S + (S - 1), 1, mk, S * q, tk, 1, S * N + xoff[tid]);
+  }
+  for (int k = tid >> 6; k < n_large; k += 4) {  // a wave per large molecule
+    const int nb = nb_s[k], a0 = a0_s[k], x0 = S * N + xoff[k];
+    for (int r = tid & 63; r < nb; r += 64) a.extra_row[a0 + r] = x0 + r;
+  }
+}
+
+// second launch of a force evaluation: x = embedding[type], x1 = (embedding lin1^T)[type] from the packed table
+// (32 lanes x 16 bytes per bead and array); its first workgroup writes the pair kernels' work items instead
+__global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restrict__ types,
+                                                         const float* __restrict__ emb,
+                                                         const float* __restrict__ emb_x1,
+                                                         float* __restrict__ x, float* __restrict__ x1,
+                                                         int64_t n_nodes, SchedArgs sa) {
+  if (blockIdx.x == 0) {  // dispatched first: runs beside the lookup
+    sched_body(sa);
+    return;
+  }
+  const int64_t total = n_nodes * 32, stride = (int64_t)(gridDim.x - 1) * 256;
+  for (int64_t idx = (int64_t)(blockIdx.x - 1) * 256 + threadIdx.x; idx < total; idx += stride) {
+    const int64_t n = idx >> 5;
+    const int c = (int)(idx & 31) * 4;
+    const int64_t ty = types[n];
+    *reinterpret_cast<f32x4*>(x + n * F + c) = *reinterpret_cast<const f32x4*>(emb + ty * F + c);
+    *reinterpret_cast<f32x4*>(x1 + n * F + c) = *reinterpret_cast<const f32x4*>(emb_x1 + ty * F + c);
+  }
+}
+
 
 // two workgroups (4 waves each) per molecule, each with half of its pair list: forces from dE/dd of the pairs,
 // energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered
@@ -463,7 +601,14 @@ int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s) {
   const int ent_cap = (int)((lds - base) / 4);
   pairs_kernel<<<dim3(2, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol_ptr, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
                                                            a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
-                                                           a.forces, ent_cap);
+                                                           a.forces, ent_cap, a.extra_row);
+  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+}
+
+int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x1, float* x, float* x1,
+                      int64_t n_nodes, const SchedArgs& sa, hipStream_t s) {
+  const int64_t want = (n_nodes * 32 + 255) / 256;
+  node_embed_kernel<<<(unsigned)(want < 4096 ? want : 4096) + 1, 256, 0, s>>>(types, emb, emb_x1, x, x1, n_nodes, sa);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
 

@@ -492,6 +492,44 @@ def test_fused_engine_random_ragged_batches(params):
     assert re < 1e-4 and rf < 1e-4
 
 
+def test_balanced_schedule_matches_static_schedule(params):
+    """128 molecules of very different sizes (60..269 beads): with 128 x 2 workgroups on 256 CUs the pair kernels run the
+    balanced work items of sched_body (large molecules hand their surplus tiles, with an extra slab, to the last
+    workgroup of a small one); n_split = 3 does not fit the chip in one round and runs the static items.  Both must
+    give the same energies and forces up to the regrouping of fp32 partial sums, and a second call the same bits."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(77)
+    sizes = [int(v) for v in torch.randint(60, 270, (128,), generator=g)]
+    sizes[3], sizes[100] = 269, 269
+    mols = []
+    for n in sizes:
+        x = torch.randn(n, 3, generator=g)
+        mols.append(x / x.norm(dim=1, keepdim=True) * 7.2 * (n / 269.0) ** (1 / 3) * torch.rand(n, 1, generator=g) ** (1 / 3))
+    pos = torch.cat(mols)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    types = torch.randint(1, 20, (pos.shape[0],), generator=g)
+    model = S.model_from_params(params).to(DEV)
+    bal, sta = engine.FusedSchNetEngine(model), engine.FusedSchNetEngine(model, n_split=3)
+    e_b, f_b = bal.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 269)
+    e_s, f_s = sta.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 269)
+    assert int(bal.status[0]) == 0 and int(sta.status[0]) == 0 and int(bal.status[2]) == int(sta.status[2])
+    re = float((e_b - e_s).abs().max() / e_s.abs().max())
+    rf = float((f_b - f_s).norm() / f_s.norm())
+    print(f"balanced vs static items, 128 ragged molecules ({pos.shape[0]} beads): energy {re:.2e} forces {rf:.2e}")
+    assert re < 2e-5 and rf < 2e-5
+    e_2, f_2 = bal.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 269)
+    assert torch.equal(e_2, e_b) and torch.equal(f_2, f_b)
+    # three of the molecules against the fp64 oracle (one of them a large one that hands tiles away)
+    for m in (3, 50, 100):
+        sl = slice(int(ptr[m]), int(ptr[m + 1]))
+        e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sl].double(), types[sl],
+                                           torch.tensor([0, sizes[m]]))
+        r_e, r_f = _relerr(e_b[m:m + 1], f_b[sl], e_o.numpy(), f_o.numpy())
+        assert r_e < 1e-4 and r_f < 1e-4, (m, r_e, r_f)
+
+
 @pytest.mark.parametrize("n_beads", [269, 300])
 def test_fused_engine_dense_molecules(params, n_beads):
     """Every bead inside every other bead's cutoff (a ball of radius 2.4 at cutoff 5): the pair list is the

@@ -52,3 +52,5 @@ for name, sl in groups:
     m = t[:, sl].mean(dim=(0, 1)) / tiles_per_wg
     print(name, "cycles per tile:", " ".join(f"[{k}]{v:.0f}" for k, v in enumerate(m.tolist())), f" sum {m.sum():.0f}")
 print(f"tiles per workgroup ~{tiles_per_wg:.1f}")
+tot = t[:, 0].sum(dim=1)   # wave 0 of every workgroup: cycles from the first barrier to the last tile
+print(f"per-workgroup cycles: mean {tot.mean():.0f}  min {tot.min():.0f}  max {tot.max():.0f}  (max / mean {tot.max() / tot.mean():.3f})")
