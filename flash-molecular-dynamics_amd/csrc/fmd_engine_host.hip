@@ -131,12 +131,14 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
     return q;
   };
   const int64_t nf = n_nodes * F * (int64_t)sizeof(float);
-  w.x = (float*)take(nf);
-  w.gx = (float*)take(nf);
-  w.gagg = (float*)take(nf);
+  // arrays the node kernels WRITE: whole 32-row tiles (their stores are unconditional, see rows_fetch)
+  const int64_t nfp = (n_nodes + 31) / 32 * 32 * F * (int64_t)sizeof(float);
+  w.x = (float*)take(nfp);
+  w.gx = (float*)take(nfp);
+  w.gagg = (float*)take(nfp);
   for (int l = 0; l < d->num_blocks; ++l) {
-    w.x1[l] = (float*)take(nf);
-    w.t[l] = (float*)take(nf);
+    w.x1[l] = (float*)take(nfp);
+    w.t[l] = (float*)take(nfp);
   }
   w.slabs = (float*)take(nf * (n_split + 1));  // the last one: extra pieces of the balanced schedule (at most N rows)
   w.e_node = (float*)take(n_nodes * 4);

@@ -24,20 +24,24 @@ struct RowsPre {
   f32x4 s0[4], s1[4];
   int er;  // row of the slab buffer with one more partial of this thread's row (sched_body), or -1
 };
+// Loads are UNCONDITIONAL (rows past the end are clamped to the last row and zeroed at commit; a missing second slab
+// re-reads the first) and stores go to arrays padded to whole tiles: with a fixed number of memory operations per tile
+// the compiler can wait for "all but the N youngest" at the top of the next tile instead of vmcnt(0), which -- the
+// counter is in order -- would also wait for the tile's last stores to reach memory (~1.5 us per tile).
+template <bool XT>
 __device__ __forceinline__ void rows_fetch(RowsPre& p, const float* __restrict__ src, int64_t slab_stride,
                                            int n_slabs, const int* __restrict__ extra_row, int64_t row0,
                                            int64_t n_rows, int tid) {
   const int r = tid >> 3, c0 = (tid & 7) * 4;
-  p.er = (extra_row && row0 + r < n_rows) ? extra_row[row0 + r] : -1;
+  const int64_t row = row0 + r < n_rows ? row0 + r : n_rows - 1;
+  p.er = -1;
+  if (XT) p.er = extra_row[row];
+  const float* q = src + row * F + c0;
+  const int64_t s1_off = n_slabs > 1 ? slab_stride : 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    p.s0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    p.s1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row0 + r < n_rows) {
-      const float* q = src + (row0 + r) * F + c0 + 32 * i;
-      p.s0[i] = *reinterpret_cast<const f32x4*>(q);
-      if (n_slabs > 1) p.s1[i] = *reinterpret_cast<const f32x4*>(q + slab_stride);
-    }
+    p.s0[i] = *reinterpret_cast<const f32x4*>(q + 32 * i);
+    p.s1[i] = *reinterpret_cast<const f32x4*>(q + 32 * i + s1_off);
   }
 }
 __device__ __forceinline__ void planes_store4(_Float16* tile, int r, int c, const f32x4& v) {
@@ -53,12 +57,14 @@ __device__ __forceinline__ void rows_commit(_Float16* tile, const RowsPre& p, co
                                             int64_t row0, int64_t n_rows, int tid) {
   const int r = tid >> 3, c0 = (tid & 7) * 4;
   // a molecule whose tiles were spread over one more workgroup (sched_body) has one more partial per row
-  const int er = extra_row ? p.er : -1;
+  const bool in = row0 + r < n_rows;
+  const int er = (extra_row && in) ? p.er : -1;
+  const float k0 = in ? 1.0f : 0.0f, k1 = (in && n_slabs > 1) ? 1.0f : 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + 32 * i;
-    f32x4 v = p.s0[i];
-    if (n_slabs > 1) v += p.s1[i];
+    f32x4 v = p.s0[i] * k0;
+    v += p.s1[i] * k1;
     if (n_slabs > 2 && row0 + r < n_rows) {
       const float* q = src + (row0 + r) * F + c;
       for (int s = 2; s < n_slabs; ++s) v += *reinterpret_cast<const f32x4*>(q + s * slab_stride);
@@ -68,20 +74,20 @@ __device__ __forceinline__ void rows_commit(_Float16* tile, const RowsPre& p, co
   }
 }
 // this lane's 16 columns of one row of a [N,128] array (zeros when the row does not exist)
-__device__ __forceinline__ f32x16 load_cols(const float* __restrict__ src, int64_t row, bool ok, int w, int h) {
+__device__ __forceinline__ f32x16 load_cols(const float* __restrict__ src, int64_t row, int64_t n_rows, int w, int h) {
   f32x16 v;
+  const int64_t rc = row < n_rows ? row : n_rows - 1;  // clamped: the load is unconditional (see rows_fetch)
+  const float k = row < n_rows ? 1.0f : 0.0f;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    if (ok) t = *reinterpret_cast<const f32x4*>(src + row * F + 32 * w + 8 * q + 4 * h);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(src + rc * F + 32 * w + 8 * q + 4 * h);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e] * k;
   }
   return v;
 }
-__device__ __forceinline__ void store_cols(float* __restrict__ dst, int64_t row, bool ok, int w, int h,
-                                           const f32x16& v) {
-  if (!ok) return;
+// (the arrays the node kernels write are padded to a multiple of 32 rows: carve_ws)
+__device__ __forceinline__ void store_cols(float* __restrict__ dst, int64_t row, int w, int h, const f32x16& v) {
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     *reinterpret_cast<f32x4*>(dst + row * F + 32 * w + 8 * q + 4 * h) =
@@ -120,22 +126,26 @@ __global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
   if (tile >= n_tiles) return;
   BFrag w1, w2, w3;
   RowsPre pre;
-  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
-  f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
+  rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
+  f32x16 xo = load_cols(a.x, tile * 32 + nl, a.n_nodes, w, h);
   load_bfrag(w2, a.l2, w, lane);
   load_bfrag(w3, a.l3, w, lane);
   load_bfrag(w1, a.l1, w, lane);
-  const f32x16 b2 = load_cols(a.b2, 0, true, w, h), b3 = load_cols(a.b3, 0, true, w, h);
+  const f32x16 b2 = load_cols(a.b2, 0, 1, w, h), b3 = load_cols(a.b3, 0, 1, w, h);
+  // The operands must have landed BEFORE the loop: left to the compiler, the wait for them sits behind the first
+  // barrier of the loop body, i.e. right after the next tile's rows are requested, in every iteration -- and the
+  // prefetch overlaps nothing (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
-    const bool ok = row < a.n_nodes;
     rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     const f32x16 x_old = xo;
-    if (next < n_tiles) {
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
-      xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
+    {  // (past the last tile: the last tile again, unused)
+      const int64_t nx = next < n_tiles ? next : n_tiles - 1;
+      rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, nx * 32, a.n_nodes, tid);
+      xo = load_cols(a.x, nx * 32 + nl, a.n_nodes, w, h);
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc = gemm_cols_frag(bufX, w2, lane);  // conv = agg lin2^T + b2
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -143,17 +153,17 @@ __global__ __launch_bounds__(256) void node_fwd_res_kernel(NodeFwdArgs a) {
       acc[r] = t[0];
       acc[r + 1] = t[1];
     }
-    store_cols(a.t_out, row, ok, w, h, acc);
+    store_cols(a.t_out, row, w, h, acc);
     cols_to_planes(bufY, acc, w, lane);
-    __syncthreads();
+    lds_barrier();
     acc = gemm_cols_frag(bufY, w3, lane);  // y = tanh(conv) lin^T + b3 ; x += y
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = x_old[r] + (acc[r] + b3[r]);
-    store_cols(a.x, row, ok, w, h, acc);
+    store_cols(a.x, row, w, h, acc);
     cols_to_planes(bufZ, acc, w, lane);
-    __syncthreads();
+    lds_barrier();
     const f32x16 x1 = gemm_cols_frag(bufZ, w1, lane);  // x1 = x lin1^T
-    store_cols(a.x1_out, row, ok, w, h, x1);
+    store_cols(a.x1_out, row, w, h, x1);
     // no barrier here: bufX / bufY / bufZ are next written after the first / second / third barrier of the next
     // tile, each of which every wave reaches only after its last read of that buffer
   }
@@ -173,21 +183,21 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
   f32x16 t_nx, gx_nx;
   auto fetch = [&](int64_t t) {
     const int64_t row = t * 32 + nl;
-    t_nx = load_cols(a.t, row, row < a.n_nodes, w, h);
+    t_nx = load_cols(a.t, row, a.n_nodes, w, h);
     if (HAS_SLABS) {
-      gx_nx = load_cols(a.gx, row, row < a.n_nodes, w, h);
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, t * 32, a.n_nodes, tid);
+      gx_nx = load_cols(a.gx, row, a.n_nodes, w, h);
+      rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, t * 32, a.n_nodes, tid);
     } else {
-      rows_fetch(pre, a.gx, 0, 1, nullptr, t * 32, a.n_nodes, tid);
+      rows_fetch<false>(pre, a.gx, 0, 1, nullptr, t * 32, a.n_nodes, tid);
     }
   };
   fetch(tile);
   if (HAS_SLABS) load_bfrag(w1, a.l1t, w, lane);
   load_bfrag(w3, a.l3t, w, lane);
   load_bfrag(w2, a.l2t, w, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // operands landed before the loop (see node_fwd_res_kernel)
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
-    const bool ok = row < a.n_nodes;
     const f32x16 t_pre = t_nx;
     f32x16 gx_pre;
     if (HAS_SLABS) {
@@ -196,25 +206,25 @@ __global__ __launch_bounds__(256) void node_bwd_res_kernel(NodeBwdArgs a) {
     } else {
       rows_commit(bufY, pre, a.gx, 0, 1, nullptr, tile * 32, a.n_nodes, tid);
     }
-    if (next < n_tiles) fetch(next);
+    fetch(next < n_tiles ? next : n_tiles - 1);  // (past the last tile: the last tile again, unused)
     f32x16 acc;
     if (HAS_SLABS) {  // gx += (sum of gx1 partials) lin1
-      __syncthreads();
+      lds_barrier();
       acc = gemm_cols_frag(bufX, w1, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = gx_pre[r] + acc[r];
-      store_cols(a.gx, row, ok, w, h, acc);
+      store_cols(a.gx, row, w, h, acc);
       cols_to_planes(bufY, acc, w, lane);
     }
-    __syncthreads();
+    lds_barrier();
     acc = gemm_cols_frag(bufY, w3, lane);  // d/d tanh(conv) = gx lin
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] *= 1.0f - t_pre[r] * t_pre[r];
     cols_to_planes(bufZ, acc, w, lane);
-    __syncthreads();
+    lds_barrier();
     acc = gemm_cols_frag(bufZ, w2, lane);  // d/d agg = gconv lin2
-    store_cols(a.gagg, row, ok, w, h, acc);
-    if (!HAS_SLABS) __syncthreads();  // bufY is refilled at the top of the next tile
+    store_cols(a.gagg, row, w, h, acc);
+    if (!HAS_SLABS) lds_barrier();  // bufY is refilled at the top of the next tile
   }
 }
 
@@ -278,10 +288,10 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     else cols_to_planes(t, v, w, lane);
   };
   RowsPre pre;
-  rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
-  f32x16 xo = load_cols(a.x, tile * 32 + nl, tile * 32 + nl < a.n_nodes, w, h);
+  rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
+  f32x16 xo = load_cols(a.x, tile * 32 + nl, a.n_nodes, w, h);
   load_bfrag(fb0, ops[0], w, lane);
-  const f32x16 b2 = load_cols(a.b2, 0, true, w, h), b3 = load_cols(a.b3, 0, true, w, h);
+  const f32x16 b2 = load_cols(a.b2, 0, 1, w, h), b3 = load_cols(a.b3, 0, 1, w, h);
   const bool col0 = w == 0 && h == 0;  // this lane's register 0 is column 0
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
@@ -289,10 +299,10 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     const f32x16 x_old = xo;
     if (more) {
-      rows_fetch(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
-      xo = load_cols(a.x, next * 32 + nl, next * 32 + nl < a.n_nodes, w, h);
+      rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
+      xo = load_cols(a.x, next * 32 + nl, a.n_nodes, w, h);
     }
-    __syncthreads();
+    lds_barrier();
     f32x16 acc = gemm(std::integral_constant<int, 0>{}, bufX, more);
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -300,14 +310,14 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
       acc[r] = t[0];
       acc[r + 1] = t[1];
     }
-    store_cols(a.t_out, row, ok, w, h, acc);
+    store_cols(a.t_out, row, w, h, acc);
     cols_to_planes(bufY, acc, w, lane);
-    __syncthreads();
+    lds_barrier();
     acc = gemm(std::integral_constant<int, 1>{}, bufY, more);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = ok ? x_old[r] + (acc[r] + b3[r]) : 0.f;
     put(bufX, acc);
-    __syncthreads();
+    lds_barrier();
     // ---- output network forward (tanh hidden layers, last layer linear without bias)
     f32x16 hk[2];
     _Float16* cur = bufX;
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     static_for<0, NUM_OUT - 1>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur, more);
-      const f32x16 bk = load_cols(a.bo[k], 0, true, w, h);
+      const f32x16 bk = load_cols(a.bo[k], 0, 1, w, h);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 t = tanh_fast2(f32x2{hk[k][r], hk[k][r + 1]} + f32x2{bk[r], bk[r + 1]});
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
         hk[k][r + 1] = t[1];
       }
       put(nxt, hk[k]);  // W16A16: hk <- f16(tanh), what the backward multiplies by
-      __syncthreads();
+      lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
     const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur, more);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     f32x16 g = zero16();
     if (col0) g[0] = 1.0f;
     put(nxt, g);
-    __syncthreads();
+    lds_barrier();
     { _Float16* tmp = cur; cur = nxt; nxt = tmp; }
     static_for<0, NUM_OUT - 1>([&](auto jc) {
       constexpr int j = decltype(jc)::value;   // operand pot[NUM_OUT-1-j], multiplies by 1 - hk[NUM_OUT-2-j]^2
@@ -341,12 +351,12 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
       put(nxt, g);  // W16A16: f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
-      __syncthreads();
+      lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
     g = gemm(std::integral_constant<int, NOPS - 1>{}, cur, more);
-    store_cols(a.gx, row, ok, w, h, g);
-    __syncthreads();
+    store_cols(a.gx, row, w, h, g);
+    lds_barrier();
   }
 }
 }  // namespace
