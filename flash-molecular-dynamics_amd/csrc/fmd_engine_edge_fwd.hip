@@ -38,7 +38,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
   float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
   float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c32 = lane & 31;
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
   int m_own, split;
@@ -49,6 +49,12 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   for (int it = 0; it < 2; ++it) {
   const int m = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it]);
   if (m < 0) break;
+  // Every per-lane quantity of the body derives from this opaque copy of the thread index: as plain loop invariants
+  // the body's address arithmetic would be hoisted in front of the item loop and stay live across BOTH roles
+  // (60 spilled registers in the backward kernel, one of them reloaded per tile on the producers' critical path).
+  int tid = tid0;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, h = lane >> 5, c32 = lane & 31;
   if (it) __syncthreads();  // the flush of the item before has read the aggregate
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
