@@ -33,11 +33,12 @@ __device__ __forceinline__ int gw_row_off(int feature, int unit) {
   return feature * 64 + 8 * (unit ^ ((feature >> 1) & 7));
 }
 typedef __fp16 fmd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-__device__ __forceinline__ f16x8 gw_frag(const char* a1, const char* a2) {
-  const fmd_h4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-      (__attribute__((address_space(3))) fmd_h4*)(uintptr_t)(uint32_t)(uintptr_t)a1);
-  const fmd_h4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-      (__attribute__((address_space(3))) fmd_h4*)(uintptr_t)(uint32_t)(uintptr_t)a2);
+typedef __attribute__((address_space(3))) fmd_h4* gw_lds_ptr;  // LDS-space pointer: constant offsets fold into the read
+__device__ __forceinline__ gw_lds_ptr gw_lds(const char* p) { return (gw_lds_ptr)(uintptr_t)(uint32_t)(uintptr_t)p; }
+template <int BYTES>
+__device__ __forceinline__ f16x8 gw_frag(gw_lds_ptr a1, gw_lds_ptr a2) {
+  const fmd_h4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(a1 + BYTES / 8);
+  const fmd_h4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16(a2 + BYTES / 8);
   f16x8 r;
   __builtin_memcpy(&r, &v0, 8);
   __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &v1, 8);
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       // ds_read_b64_tr_b16 -- lane 4q+p of a group addresses row (feature) f0 + q, pairs 16 g + 4p .. + 3
       const int tg = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
       const char* gw_img = reinterpret_cast<const char*>(hid_hi);
-      const char* gw_a1 = gw_img + gw_row_off(16 * ku0 + 8 * h + tq, 4 * tg + tp);
-      const char* gw_a2 = gw_img + gw_row_off(16 * ku0 + 8 * h + 4 + tq, 4 * tg + tp);
+      const gw_lds_ptr gw_a1 = gw_lds(gw_img + gw_row_off(16 * ku0 + 8 * h + tq, 4 * tg + tp));
+      const gw_lds_ptr gw_a2 = gw_lds(gw_img + gw_row_off(16 * ku0 + 8 * h + 4 + tq, 4 * tg + tp));
       // meta of the tile to stage next (lane = pair view)
       float d_n, c_n, dc_n, gd_n = 0.f;
       auto fetch = [&](int t) {
@@ -139,12 +140,15 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       // staged tile ("nx") and tile whose reduction is pending ("cu")
       f16x4 hh[4], hl[4];
       // k = d(message weight)/dd per unit u: C (1-h^2) z' + C' h   (one array: registers are tight)
-      float k_nx[16], gd_nx = 0.f;
-      float k_cu[16], gd_cu = 0.f;
+      // two sets, staged ("nx") and pending ("cu"), that swap roles from tile to tile (the tile loop is unrolled by two:
+      // copying nx -> cu cost 17 moves per tile on the producers' critical path)
+      struct KSet { float k[16]; float gd; };
+      KSet ks_a, ks_b;
+      ks_a.gd = 0.f; ks_b.gd = 0.f;
       const float gl = a.gamma * LOG2E;
-      auto compute = [&](int t_fetch) {
+      auto compute = [&](int t_fetch, KSet& nx) {
         const float d = d_n, C = c_n, dC = dc_n;
-        gd_nx = gd_n;
+        nx.gd = gd_n;
         fetch(t_fetch);
         f32x16 z1 = zero16(), p1 = zero16();
         if (SHARE) {
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             else split_pair_u(ch, th[ep], tl[ep]);
             // k = d(C h)/dd = C (1 - h^2) z' + C' h = (C - (C h) h) z' + C' h
             const f32x2 kk = (splat2(C) - ch * hv) * zp + splat2(dC) * hv;
-            k_nx[r] = kk[0];
-            k_nx[r + 1] = kk[1];
+            nx.k[r] = kk[0];
+            nx.k[r + 1] = kk[1];
           }
           __builtin_memcpy(&hh[q], th, 8);
           __builtin_memcpy(&hl[q], tl, 8);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // ... and the k array too: left alone, the compiler sinks its arithmetic behind the reduction
         // and carries both accumulators of G1 and the hidden values (48 registers) across it instead
 #pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(k_nx[r]));
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(nx.k[r]));
       };
       auto put = [&]() {
 #pragma unroll
@@ -225,21 +229,15 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
-      auto rotate = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) k_cu[r] = k_nx[r];
-        gd_cu = gd_nx;
-      };
       fetch(T0);
       if (SHARE) __syncthreads();  // fragments of the first tile visible
-      compute(T0 + S);
+      compute(T0 + S, ks_a);
       if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
-      rotate();
       put();
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < t_end; t += S) {
-        if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // stages tile t+S while the consumers contract tile t
+      auto tile = [&](int t, KSet& cu, KSet& nx) {
+        if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S, nx);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
         __syncthreads();     // B(t)
         FMD_MARK(1)
@@ -250,14 +248,14 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         {
           // gW fragments: two transposed reads (features 8h + 0..3 and 8h + 4..7 of the k-step) per plane, one
           // k-step ahead of their MFMAs (fenced: see the consumers' L1 loop)
-          f16x8 bh = gw_frag(gw_a1, gw_a2), bl = bh;
-          if (!HALF) bl = gw_frag(gw_a1 + GW_PLANE, gw_a2 + GW_PLANE);
+          f16x8 bh = gw_frag<0>(gw_a1, gw_a2), bl = bh;
+          if (!HALF) bl = gw_frag<GW_PLANE>(gw_a1, gw_a2);
           static_for<0, NKU>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             f16x8 nh = bh, nl = bl;
             if constexpr (s + 1 < NKU) {
-              nh = gw_frag(gw_a1 + 1024 * (s + 1), gw_a2 + 1024 * (s + 1));
-              if (!HALF) nl = gw_frag(gw_a1 + GW_PLANE + 1024 * (s + 1), gw_a2 + GW_PLANE + 1024 * (s + 1));
+              nh = gw_frag<1024 * (s + 1)>(gw_a1, gw_a2);
+              if (!HALF) nl = gw_frag<GW_PLANE + 1024 * (s + 1)>(gw_a1, gw_a2);
             }
             mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
             bh = nh; bl = nl;
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const f32x2 pr = comb2<HALF>(u1, u2, r) *
-                           f32x2{k_cu[r], k_cu[r + 1]};
+                           f32x2{cu.k[r], cu.k[r + 1]};
           tot += pr[0] + pr[1];
         }
         tot = fmd_xor32_sum(tot);
@@ -279,13 +277,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_MARK(4)
         if (w == 0 && h == 0) {
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
-          pgd[t * 32 + c32] = FIRST ? sum : gd_cu + sum;
+          pgd[t * 32 + c32] = FIRST ? sum : cu.gd + sum;
         }
         put();               // hidden tiles of t+S
-        rotate();
         FMD_MARK(5)
         __syncthreads();     // A(t+S)
         FMD_MARK(6)
+      };
+      for (int t = T0; t < t_end; t += 2 * S) {
+        tile(t, ks_a, ks_b);
+        if (t + S >= t_end) break;
+        tile(t + S, ks_b, ks_a);
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
