@@ -263,13 +263,19 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           });
         }
         // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
-        float tot = 0.f;
+        // sum_r (u1_r + u2_r / 2048) k_r as two fma chains per accumulator and one recombination (the per-register
+        // recombination cost 16 more instructions on the producers' critical path)
+        float ta = 0.f, tb = 0.f, tc = 0.f, td = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 pr = comb2<HALF>(u1, u2, r) *
-                           f32x2{cu.k[r], cu.k[r + 1]};
-          tot += pr[0] + pr[1];
+          ta = __builtin_fmaf(u1[r], cu.k[r], ta);
+          tb = __builtin_fmaf(u1[r + 1], cu.k[r + 1], tb);
+          if (!HALF) {
+            tc = __builtin_fmaf(u2[r], cu.k[r], tc);
+            td = __builtin_fmaf(u2[r + 1], cu.k[r + 1], td);
+          }
         }
+        float tot = (ta + tb) + (tc + td) * (1.0f / 2048.0f);
         tot = fmd_xor32_sum(tot);
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_MARK(3)
