@@ -29,8 +29,8 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 // features per row, so each of the molecule's TWO workgroups keeps 64 features of it (blockIdx.x = which half),
 // walks ALL tiles, stages the full hidden tile (the producers' work is done twice per molecule) and runs two
 // consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
-// SH: the tile's Gaussians are computed once, by the consumers (consumer w: k-step w) between barriers B and A,
-// and reach the producers as split fragments in LDS (see the backward kernel); used when the region fits.
+// SH: the tile's Gaussians are computed once per workgroup (producer w: k-step w, while it would wait for barrier B),
+// and reach all producers as split fragments in LDS (see the backward kernel); used when the region fits.
 template <int NS0, bool HALF, bool FS, bool SH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -154,18 +154,53 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
-      if (SH) __syncthreads();  // fragments of the first tile visible
+      // SH: the Gaussians of a tile are formed ONCE per workgroup, k-step w by producer wave w, as split fragments in
+      // LDS.  The consumers' chain (L1 + aggregate update) is the longer one between A and B, so the producers form
+      // the fragments of the tile after next in the time they would wait for B (d_n holds that tile's distances once
+      // compute() has run), keep them in eight registers and write them next to the hidden tile after B.
+      f16x8 fr_h, fr_l;
+      f32x4 cs0, cs1;
+      const bool shares = SH && w < NS0 && 2 * w + h < a.nb;
+      if (shares) {
+        cs0 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h);
+        cs1 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h + 4);
+      }
+      auto gauss = [&]() {  // of the tile whose distances d_n holds
+        if (shares) {
+          f16x8 ph, pl;
+          rbf_fragments<false, HALF>(d_n, gl, cs0, cs1, fr_h, fr_l, ph, pl);
+          asm volatile("" : "+v"(fr_h), "+v"(fr_l));  // formed here, not sunk behind the barrier
+        }
+      };
+      auto put_frags = [&]() {
+        if (shares) {
+          const int blk = 2 * w + h;
+          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = fr_h;
+          if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = fr_l;
+        }
+      };
+      if (SH) {
+        gauss();          // first tile (d_n as fetched above)
+        put_frags();
+        __syncthreads();  // its fragments visible
+      }
       compute(T0 + S);
-      if (SH) __syncthreads();  // ... and consumed: the consumers write the second tile's
+      if (SH) {
+        gauss();          // second tile
+        __syncthreads();  // the first tile's fragments consumed
+        put_frags();
+      }
       put();
       __syncthreads();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < t_end; t += S) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
+        if (SH) gauss();     // tile t+2S
         FMD_MARK(0)
         __syncthreads();     // B(t)
         FMD_MARK(1)
         put();
+        if (SH) put_frags();
         FMD_MARK(2)
         __syncthreads();     // A(t+S)
         FMD_MARK(3)
@@ -245,33 +280,9 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
       // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
       // between the two barriers where the producers only write LDS.
-      // SH: Gaussians of one tile (k-step w of this wave) as split fragments in LDS
-      float d_m = 0.f;
-      f32x4 cs0, cs1;
-      if (SH && w < NS0) {
-        cs0 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h);
-        cs1 = *reinterpret_cast<const f32x4*>(a.centers + 16 * w + 8 * h + 4);
-      }
-      auto fetch_d = [&](int t) {
-        if (SH) d_m = pdist[min(t * 32, last_base) + c32];
-      };
-      auto share_fragments = [&]() {  // of the tile whose distances were fetched last
-        if (SH && w < NS0 && 2 * w + h < a.nb) {
-          f16x8 bh, bl, ph, pl;
-          rbf_fragments<false, HALF>(d_m, a.gamma * LOG2E, cs0, cs1, bh, bl, ph, pl);
-          const int blk = 2 * w + h;
-          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
-          if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = bl;
-        }
-      };
-      if (SH) {
-        fetch_d(T0);
-        share_fragments();
-        fetch_d(T0 + S);
-        __syncthreads();  // first tile's fragments visible
-        __syncthreads();  // ... and consumed
-        share_fragments();
-        fetch_d(T0 + 2 * S);
+      if (SH) {  // the producers' fragment hand-over (see there): two more barriers before the first tile
+        __syncthreads();
+        __syncthreads();
       }
       fetch_meta(T0);
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
@@ -354,10 +365,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         FMD_MARK(2)
         __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(3)
-        if (SH) {  // the producers only write the hidden tile now: the fragments they stage from next are replaced
-          share_fragments();
-          fetch_d(t + 3 * S);
-        }
         FMD_MARK(4)
         __syncthreads();  // A(t+S)
         FMD_MARK(5)
