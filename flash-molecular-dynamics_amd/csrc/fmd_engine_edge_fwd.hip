@@ -221,12 +221,25 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
         if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
       }
-      const uint32_t col4 = (uint32_t)(32 * cw + c32) * 4u;
-      // byte offset inside the LDS aggregate of the row/column a global offset o = row * 512 + col4 names
-      const int lds_adj = (32 * w + c32) * 4 - (int)(col4 >> 1);
-      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
-      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
+      // Whole-aggregate mode: a row offset o = row * 512 + column carries the aggregate's LDS address as well, so it is
+      // the LDS address of the aggregate element as it stands (no add per access: 20 per tile on the consumers' chain,
+      // which is the longer one here) and, against a base moved back by the same amount, the offset of the x1 gather.
+      typedef __attribute__((address_space(3))) float* lds_fp;
+      const uint32_t agg_lds = FS ? 0u : (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(agg);
+      const uint32_t colp = (uint32_t)(32 * cw + c32) * 4u;
+      const uint32_t col4 = colp + agg_lds;
+      // FS: byte offset inside the LDS aggregate of the row/column a global offset o = row * 512 + col4 names
+      const int lds_adj = (32 * w + c32) * 4 - (int)(colp >> 1);
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F) - agg_lds;
       char* aggb = reinterpret_cast<char*>(agg);
+      auto agg_rd = [&](uint32_t o) -> float {
+        if (FS) return *reinterpret_cast<const float*>(aggb + (uint32_t)((int)(o >> 1) + lds_adj));
+        return *(lds_fp)(uintptr_t)o;
+      };
+      auto agg_wr = [&](uint32_t o, float v) {
+        if (FS) *reinterpret_cast<float*>(aggb + (uint32_t)((int)(o >> 1) + lds_adj)) = v;
+        else *(lds_fp)(uintptr_t)o = v;
+      };
       SegRegs X;
       uint32_t oj_m[16], oi_m[4];
       auto fetch_meta = [&](int t) {
@@ -265,16 +278,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             Wq[e] = fl[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
-            vj[e] = *reinterpret_cast<const float*>(aggb + lo(X.oj[4 * q + e]));
+            vj[e] = agg_rd(X.oj[4 * q + e]);
             si += X.xj[4 * q + e] * Wq[e];
           }
-          const float cval = *reinterpret_cast<const float*>(aggb + lo(X.oi[q]));
+          const float cval = agg_rd(X.oi[q]);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wq[e];
+            agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wq[e]);
           si = fmd_segment_sum(si, X.oi[q]);
           // both halves store the same value to the same address
-          *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
+          agg_wr(X.oi[q], cval + si);
         });
       };
       // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
@@ -321,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           auto seg_reads = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vj[e] = *reinterpret_cast<const float*>(aggb + lo(X.oj[4 * q + e]));
-            cval = *reinterpret_cast<const float*>(aggb + lo(X.oi[q]));
+            for (int e = 0; e < 4; ++e) vj[e] = agg_rd(X.oj[4 * q + e]);
+            cval = agg_rd(X.oi[q]);
           };
           auto seg_finish = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -331,11 +344,11 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             for (int e = 0; e < 4; ++e) {
               const float Wqe = fl_prev[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
               si += X.xj[4 * q + e] * Wqe;
-              *reinterpret_cast<float*>(aggb + lo(X.oj[4 * q + e])) = vj[e] + X.xi[q] * Wqe;
+              agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wqe);
             }
             si = fmd_segment_sum(si, X.oi[q]);
             // both halves store the same value to the same address
-            *reinterpret_cast<float*>(aggb + lo(X.oi[q])) = cval + si;
+            agg_wr(X.oi[q], cval + si);
           };
           auto seg_refill = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
