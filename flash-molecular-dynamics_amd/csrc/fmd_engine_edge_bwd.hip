@@ -306,12 +306,23 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
       }
       const int col = 32 * cw + c32;
-      const uint32_t col4 = (uint32_t)col * 4u;
-      const int lds_adj = (32 * (w & 1) + c32) * 4 - (int)(col4 >> 1);
-      auto lo = [&](uint32_t o) -> uint32_t { return FS ? (uint32_t)((int)(o >> 1) + lds_adj) : o; };
-      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F);
-      const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F);
+      // whole-aggregate mode: the row offsets carry the LDS address of the gx1 aggregate (see the forward kernel)
+      typedef __attribute__((address_space(3))) float* lds_fp;
+      const uint32_t agg_lds = (FS || !NEED_GX1) ? 0u : (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(gx1);
+      const uint32_t colp = (uint32_t)col * 4u;
+      const uint32_t col4 = colp + agg_lds;
+      const int lds_adj = (32 * (w & 1) + c32) * 4 - (int)(colp >> 1);
+      const char* x1b = reinterpret_cast<const char*>(a.x1 + a0 * F) - agg_lds;
+      const char* gab = reinterpret_cast<const char*>(a.gagg + a0 * F) - agg_lds;
       char* gx1b = reinterpret_cast<char*>(gx1);
+      auto agg_rd = [&](uint32_t o) -> float {
+        if (FS) return *reinterpret_cast<const float*>(gx1b + (uint32_t)((int)(o >> 1) + lds_adj));
+        return *(lds_fp)(uintptr_t)o;
+      };
+      auto agg_wr = [&](uint32_t o, float v) {
+        if (FS) *reinterpret_cast<float*>(gx1b + (uint32_t)((int)(o >> 1) + lds_adj)) = v;
+        else *(lds_fp)(uintptr_t)o = v;
+      };
       SegRegsB X;
       uint32_t oj_m[16], oi_m[4];
       float d_m = 0.f;  // SHARE: distance of pair c32 of the fetched tile
@@ -445,8 +456,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           constexpr int q = decltype(qc)::value;
           if (NEED_GX1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vj[e] = *reinterpret_cast<const float*>(gx1b + lo(X.oj[4 * q + e]));
-            cval = *reinterpret_cast<const float*>(gx1b + lo(X.oi[q]));
+            for (int e = 0; e < 4; ++e) vj[e] = agg_rd(X.oj[4 * q + e]);
+            cval = agg_rd(X.oi[q]);
           }
         };
         auto seg_finish = [&](auto qc) {
@@ -457,10 +468,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             for (int e = 0; e < 4; ++e) {
               const float Wqe = fl[4 * q + e];  // already filt * C
               si += X.gj[4 * q + e] * Wqe;
-              *reinterpret_cast<float*>(gx1b + lo(X.oj[4 * q + e])) = vj[e] + X.gi[q] * Wqe;
+              agg_wr(X.oj[4 * q + e], vj[e] + X.gi[q] * Wqe);
             }
             si = fmd_segment_sum(si, X.oi[q]);
-            *reinterpret_cast<float*>(gx1b + lo(X.oi[q])) = cval + si;
+            agg_wr(X.oi[q], cval + si);
           }
         };
         auto seg_refill = [&](auto qc) {  // segment q of X <- tile t+S (offsets fetched one tile ago)
