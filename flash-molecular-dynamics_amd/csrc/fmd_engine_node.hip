@@ -273,15 +273,19 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     ops[2 + k] = a.po[k];
     ops[2 + NUM_OUT + k] = a.pot[NUM_OUT - 1 - k];
   }
+  // Operand idx lives in buffer idx & 1.  The request for operand idx + 2 goes out right BEHIND GEMM idx, into the
+  // buffer that GEMM has just read: it then has the whole next stage plus this stage's epilogue to arrive (requested
+  // at the start of GEMM idx + 1, as before, it had one GEMM: every stage waited ~1 us for its operand).  All requests
+  // are unconditional (past the last tile they re-read operands 0 and 1) so that the compiler can count them.
   BFrag fb0, fb1;
-  auto gemm = [&](auto idx_c, const _Float16* t, bool more_tiles) -> f32x16 {
+  auto gemm = [&](auto idx_c, const _Float16* t) -> f32x16 {
     constexpr int idx = decltype(idx_c)::value;
     BFrag& cur = (idx & 1) ? fb1 : fb0;
-    BFrag& nxt = (idx & 1) ? fb0 : fb1;
-    if constexpr (idx + 1 < NOPS) load_bfrag(nxt, ops[idx + 1], w, lane);
-    else if (more_tiles) load_bfrag(nxt, ops[0], w, lane);  // NOPS is even: nxt is fb0 again
-    if constexpr (HOUT && idx >= 2) return gemm_cols_half(t, cur, lane);
-    else return gemm_cols_frag(t, cur, lane);
+    f32x16 r;
+    if constexpr (HOUT && idx >= 2) r = gemm_cols_half(t, cur, lane);
+    else r = gemm_cols_frag(t, cur, lane);
+    load_bfrag(cur, ops[(idx + 2) % NOPS], w, lane);  // NOPS is even: the next tile's operands 0, 1 land in fb0, fb1
+    return r;
   };
   auto put = [&](_Float16* t, f32x16& v) {  // the output network's activations
     if (HOUT) cols_to_plane_half(t, v, w, lane);
@@ -291,19 +295,22 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
   rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
   f32x16 xo = load_cols(a.x, tile * 32 + nl, a.n_nodes, w, h);
   load_bfrag(fb0, ops[0], w, lane);
+  load_bfrag(fb1, ops[1], w, lane);
   const f32x16 b2 = load_cols(a.b2, 0, 1, w, h), b3 = load_cols(a.b3, 0, 1, w, h);
   const bool col0 = w == 0 && h == 0;  // this lane's register 0 is column 0
+  // the hidden layers' biases stay in registers: loaded inside the tile loop, each stage's wait for its 64 bytes of
+  // bias was a wait for every operand request in flight as well (the counter is in order)
+  f32x16 bo_r[NUM_OUT - 1];
+#pragma unroll
+  for (int k = 0; k < NUM_OUT - 1; ++k) bo_r[k] = load_cols(a.bo[k], 0, 1, w, h);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // everything requested so far has landed (see node_fwd_res_kernel)
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
-    const bool ok = row < a.n_nodes, more = next < n_tiles;
+    const bool ok = row < a.n_nodes;
     rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
     const f32x16 x_old = xo;
-    if (more) {
-      rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, next * 32, a.n_nodes, tid);
-      xo = load_cols(a.x, next * 32 + nl, a.n_nodes, w, h);
-    }
     lds_barrier();
-    f32x16 acc = gemm(std::integral_constant<int, 0>{}, bufX, more);
+    f32x16 acc = gemm(std::integral_constant<int, 0>{}, bufX);
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       const f32x2 t = tanh_fast2(f32x2{acc[r], acc[r + 1]} + f32x2{b2[r], b2[r + 1]});
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     store_cols(a.t_out, row, w, h, acc);
     cols_to_planes(bufY, acc, w, lane);
     lds_barrier();
-    acc = gemm(std::integral_constant<int, 1>{}, bufY, more);
+    acc = gemm(std::integral_constant<int, 1>{}, bufY);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = ok ? x_old[r] + (acc[r] + b3[r]) : 0.f;
     put(bufX, acc);
@@ -324,8 +331,8 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     _Float16* nxt = bufY;
     static_for<0, NUM_OUT - 1>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur, more);
-      const f32x16 bk = load_cols(a.bo[k], 0, 1, w, h);
+      hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur);
+      const f32x16& bk = bo_r[k];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 t = tanh_fast2(f32x2{hk[k][r], hk[k][r + 1]} + f32x2{bk[r], bk[r + 1]});
@@ -336,8 +343,15 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
       lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
-    const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur, more);
+    const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur);
     if (col0 && ok) a.e_node[row] = e[0];
+    {  // The next tile's rows are requested HERE: behind the only conditional store of the tile (what is older than a
+       // request does not enter the count of operations the wait for it may leave outstanding) and three stages
+       // ahead of their use.  Past the last tile: the last tile again, unused.
+      const int64_t nx = next < n_tiles ? next : n_tiles - 1;
+      rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, nx * 32, a.n_nodes, tid);
+      xo = load_cols(a.x, nx * 32 + nl, a.n_nodes, w, h);
+    }
     // ---- output network backward: dE/de = 1 in column 0
     f32x16 g = zero16();
     if (col0) g[0] = 1.0f;
@@ -347,14 +361,14 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     static_for<0, NUM_OUT - 1>([&](auto jc) {
       constexpr int j = decltype(jc)::value;   // operand pot[NUM_OUT-1-j], multiplies by 1 - hk[NUM_OUT-2-j]^2
       constexpr int k = NUM_OUT - 1 - j;
-      g = gemm(std::integral_constant<int, 2 + NUM_OUT + j>{}, cur, more);
+      g = gemm(std::integral_constant<int, 2 + NUM_OUT + j>{}, cur);
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
       put(nxt, g);  // W16A16: f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
       lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
-    g = gemm(std::integral_constant<int, NOPS - 1>{}, cur, more);
+    g = gemm(std::integral_constant<int, NOPS - 1>{}, cur);
     store_cols(a.gx, row, w, h, g);
     lds_barrier();
   }
