@@ -492,6 +492,46 @@ def test_fused_engine_random_ragged_batches(params):
     assert re < 1e-4 and rf < 1e-4
 
 
+@pytest.mark.parametrize("shape", ["one_large", "b256"])
+def test_balanced_schedule_extreme_batches(params, shape):
+    """The balanced work items where the pairing is lopsided: one 269-bead molecule among 127 of 8..14 beads (the
+    large one's surplus is most of its list and lands on a tiny molecule's workgroup), and 256 molecules with one
+    workgroup each (n_split resolves to 1).  Checked against the static items (n_split given explicitly)."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(5)
+    if shape == "one_large":
+        sizes = [int(v) for v in torch.randint(8, 15, (128,), generator=g)]
+        sizes[77] = 269
+        static_split = 3
+    else:
+        sizes = [int(v) for v in torch.randint(20, 120, (256,), generator=g)]
+        static_split = 2
+    mols = []
+    for n in sizes:
+        x = torch.randn(n, 3, generator=g)
+        mols.append(x / x.norm(dim=1, keepdim=True) * 7.2 * (n / 269.0) ** (1 / 3) * torch.rand(n, 1, generator=g) ** (1 / 3))
+    pos = torch.cat(mols)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    types = torch.randint(1, 20, (pos.shape[0],), generator=g)
+    model = S.model_from_params(params).to(DEV)
+    bal, sta = engine.FusedSchNetEngine(model), engine.FusedSchNetEngine(model, n_split=static_split)
+    e_b, f_b = bal.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), max(sizes))
+    e_s, f_s = sta.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), max(sizes))
+    assert int(bal.status[0]) == 0 and int(sta.status[0]) == 0 and int(bal.status[2]) == int(sta.status[2])
+    re = float((e_b - e_s).abs().max() / e_s.abs().max())
+    rf = float((f_b - f_s).norm() / f_s.norm())
+    print(f"{shape}: balanced vs static items, energy {re:.2e} forces {rf:.2e}")
+    assert re < 2e-5 and rf < 2e-5
+    m = 77 if shape == "one_large" else 200
+    sl = slice(int(ptr[m]), int(ptr[m + 1]))
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sl].double(), types[sl],
+                                       torch.tensor([0, sizes[m]]))
+    r_e, r_f = _relerr(e_b[m:m + 1], f_b[sl], e_o.numpy(), f_o.numpy())
+    assert r_e < 1e-4 and r_f < 1e-4, (r_e, r_f)
+
+
 def test_balanced_schedule_matches_static_schedule(params):
     """128 molecules of very different sizes (60..269 beads): with 128 x 2 workgroups on 256 CUs the pair kernels run the
     balanced work items of sched_body (large molecules hand their surplus tiles, with an extra slab, to the last
