@@ -1,12 +1,12 @@
 #!/bin/bash
 # Same-box A/B of library variants: tools/ab_libs.sh gpurun_ab/lib_a.so gpurun_ab/lib_b.so ...  (two passes over all of
-# them; each run is bench.py --no-cpu-baseline with the variant copied over the in-tree library; the original comes back)
+# them; each run is bench.py --no-cpu-baseline $BENCH_ARGS with the variant copied over the in-tree library; the original comes back)
 LIB=flash-molecular-dynamics_amd/flashmd_amd/libflashmd_hip.so
 cp $LIB /tmp/lib_orig.so
 for pass in 1 2; do
   for v in "$@"; do
     cp $v $LIB
-    timeout -k 10 200 python bench.py --no-cpu-baseline > /tmp/ab.json 2>/dev/null
+    timeout -k 10 200 python bench.py --no-cpu-baseline $BENCH_ARGS > /tmp/ab.json 2>/dev/null
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))
