@@ -205,7 +205,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             const f32x2 hv = tanh_from_scaled2(splat2(C2) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
             // the tile carries C h: L1 then yields W = filt C
             const f32x2 ch = splat2(C) * hv;
-            if (HALF) { th[ep] = half_pair(ch); tl[ep] = 0; }
+            if constexpr (!NEED_GX1) { th[ep] = 0; tl[ep] = 0; }  // no L1 in block 0: no hidden tile
+            else if (HALF) { th[ep] = half_pair(ch); tl[ep] = 0; }
             else split_pair_u(ch, th[ep], tl[ep]);
             // k = d(C h)/dd = C (1 - h^2) z' + C' h = (C - (C h) h) z' + C' h
             const f32x2 kk = (splat2(C) - ch * hv) * zp + splat2(dC) * hv;
@@ -223,10 +224,12 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(nx.k[r]));
       };
       auto put = [&]() {
+        if constexpr (NEED_GX1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
-          if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+          for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+            if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
+          }
         }
       };
       fetch(T0);
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_MARK(0)
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
-        {
+        if constexpr (NEED_GX1) {  // (block 0 has no gx1: the filter values and the hidden tile are not needed at all)
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
           const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
