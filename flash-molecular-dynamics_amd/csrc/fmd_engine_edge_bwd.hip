@@ -61,6 +61,14 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   // Wc = W0 diag(centre - c0) on the same fragments (W0 (raw (d - centre)) = (d - c0) W0 raw - Wc raw).
   float* frag_l = b0_l + 128;                                    // [nb][2][32] x 16 B   (SHARE only)
   float* gx1 = frag_l + (SHARE ? a.nb * 256 : 0);                // [n][128]
+  // PIPE (block 0: no gx1 aggregate, hence no hidden tile, no L1 and an almost empty LDS): the gW image, the shared
+  // fragments and the partial sums are double-buffered, and ONE barrier per tile separates "the consumers hand over
+  // gW(t+1) and the Gaussians of t+2" from "the producers stage k(t+1) and run the u GEMM of t" -- instead of the four
+  // phases the single tile region forces on the other blocks (the producers there wait ~15 % of the tile).
+  constexpr bool PIPE = !NEED_GX1 && SHARE && !FS;
+  float* frag_l2 = gx1;                                          // PIPE: second fragment buffer
+  float* gw_img2f = frag_l2 + a.nb * 256;                        // PIPE: second gW image (2 planes, 16 KB)
+  float* red2 = gw_img2f + 4096;                                 // PIPE: second [4][32] partial sums
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       KSet ks_a, ks_b;
       ks_a.gd = 0.f; ks_b.gd = 0.f;
       const float gl = a.gamma * LOG2E;
+      const float* frag_cur = frag_l;  // fragment buffer compute() reads (PIPE alternates it)
       auto compute = [&](int t_fetch, KSet& nx) {
         const float d = d_n, C = c_n, dC = dc_n;
         nx.gd = gd_n;
@@ -154,9 +163,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (SHARE) {
           // shared fragments: p accumulates Gc = Wc raw.  The fragments of k-step s+1 are requested before the MFMAs
           // of k-step s (an LDS round trip per k-step would otherwise sit in front of every group of MFMAs).
+          const float* fbuf = frag_cur;
           auto frag_rd = [&](int s_, int rec) {
             const int blk = min(2 * s_ + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
-            return *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + rec) * 32 + c32) * 4);
+            return *reinterpret_cast<const f16x8*>(fbuf + ((blk * 2 + rec) * 32 + c32) * 4);
           };
           f16x8 bh = frag_rd(0, 0), bl = frag_rd(0, 1);
           static_for<0, NS0>([&](auto sc) {
@@ -232,7 +242,67 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           }
         }
       };
+      // u^T slice = W1^T slice . gW^T and the reduction against k: partial sums of this wave's 32 hidden features
+      auto u_gemm_reduce = [&](gw_lds_ptr g1, gw_lds_ptr g2, const KSet& cu) -> float {
+        f32x16 u1 = zero16(), u2 = zero16();
+        f16x8 bh = gw_frag<0>(g1, g2), bl = bh;
+        if (!HALF) bl = gw_frag<GW_PLANE>(g1, g2);
+        static_for<0, NKU>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          f16x8 nh = bh, nl = bl;
+          if constexpr (s + 1 < NKU) {
+            nh = gw_frag<1024 * (s + 1)>(g1, g2);
+            if (!HALF) nl = gw_frag<GW_PLANE + 1024 * (s + 1)>(g1, g2);
+          }
+          mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
+          bh = nh; bl = nl;
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        float ta = 0.f, tb = 0.f, tc = 0.f, td = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          ta = __builtin_fmaf(u1[r], cu.k[r], ta);
+          tb = __builtin_fmaf(u1[r + 1], cu.k[r + 1], tb);
+          if (!HALF) {
+            tc = __builtin_fmaf(u2[r], cu.k[r], tc);
+            td = __builtin_fmaf(u2[r + 1], cu.k[r + 1], td);
+          }
+        }
+        return fmd_xor32_sum((ta + tb) + (tc + td) * (1.0f / 2048.0f));
+      };
       fetch(T0);
+      if constexpr (PIPE) {
+        // step i (tile t): k(t+S) from the fragments the consumers wrote two steps ago, u GEMM of t from the image they
+        // wrote in the step before, partial sums -> red[i & 1]; after the step's barrier wave 0 adds them up.
+        const gw_lds_ptr gw_b1 = gw_a1 + (reinterpret_cast<const char*>(gw_img2f) - reinterpret_cast<const char*>(hid_hi)) / 8;
+        const gw_lds_ptr gw_b2 = gw_a2 + (reinterpret_cast<const char*>(gw_img2f) - reinterpret_cast<const char*>(hid_hi)) / 8;
+        __syncthreads();  // P0: fragments of the first two tiles and gW of the first tile visible
+        frag_cur = frag_l;
+        compute(T0 + S, ks_a);  // k of the first tile
+        __syncthreads();  // P1: the first tile's fragments consumed (the consumers replace them in step 0)
+        FMD_MARK(11)
+        auto ptile = [&](int t, auto odd, KSet& cu, KSet& nx) {
+          constexpr bool ODD = decltype(odd)::value;
+          frag_cur = ODD ? frag_l : frag_l2;  // tile t+S
+          if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S, nx);
+          FMD_MARK(0)
+          const float tot = ODD ? u_gemm_reduce(gw_b1, gw_b2, cu) : u_gemm_reduce(gw_a1, gw_a2, cu);
+          float* rbuf = ODD ? red2 : red;
+          if (h == 0) rbuf[w * 32 + c32] = tot;
+          FMD_MARK(3)
+          __syncthreads();   // the step's only barrier
+          FMD_MARK(4)
+          if (w == 0 && h == 0) {
+            const float sum = ((rbuf[c32] + rbuf[32 + c32]) + rbuf[64 + c32]) + rbuf[96 + c32];
+            pgd[t * 32 + c32] = FIRST ? sum : cu.gd + sum;
+          }
+        };
+        for (int t = T0; t < t_end; t += 2 * S) {
+          ptile(t, std::false_type{}, ks_a, ks_b);
+          if (t + S >= t_end) break;
+          ptile(t + S, std::true_type{}, ks_b, ks_a);
+        }
+      } else {
       if (SHARE) __syncthreads();  // fragments of the first tile visible
       compute(T0 + S, ks_a);
       if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
@@ -246,40 +316,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_MARK(1)
         __syncthreads();     // C(t): gW(t) visible
         FMD_MARK(2)
-        // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features)
-        f32x16 u1 = zero16(), u2 = zero16();
-        {
-          // gW fragments: two transposed reads (features 8h + 0..3 and 8h + 4..7 of the k-step) per plane, one
-          // k-step ahead of their MFMAs (fenced: see the consumers' L1 loop)
-          f16x8 bh = gw_frag<0>(gw_a1, gw_a2), bl = bh;
-          if (!HALF) bl = gw_frag<GW_PLANE>(gw_a1, gw_a2);
-          static_for<0, NKU>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            f16x8 nh = bh, nl = bl;
-            if constexpr (s + 1 < NKU) {
-              nh = gw_frag<1024 * (s + 1)>(gw_a1, gw_a2);
-              if (!HALF) nl = gw_frag<GW_PLANE + 1024 * (s + 1)>(gw_a1, gw_a2);
-            }
-            mfma_prod<HALF>(wth[s], wtl[s], bh, bl, u1, u2);
-            bh = nh; bl = nl;
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-        // dE/dd = C sum_h u (1-h^2) z'  +  C' sum_h u h   (this wave's 32 hidden features)
-        // sum_r (u1_r + u2_r / 2048) k_r as two fma chains per accumulator and one recombination (the per-register
-        // recombination cost 16 more instructions on the producers' critical path)
-        float ta = 0.f, tb = 0.f, tc = 0.f, td = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          ta = __builtin_fmaf(u1[r], cu.k[r], ta);
-          tb = __builtin_fmaf(u1[r + 1], cu.k[r + 1], tb);
-          if (!HALF) {
-            tc = __builtin_fmaf(u2[r], cu.k[r], tc);
-            td = __builtin_fmaf(u2[r + 1], cu.k[r + 1], td);
-          }
-        }
-        float tot = (ta + tb) + (tc + td) * (1.0f / 2048.0f);
-        tot = fmd_xor32_sum(tot);
+        // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features); dE/dd = C sum_h u (1-h^2) z' + C' sum_h u h
+        const float tot = u_gemm_reduce(gw_a1, gw_a2, cu);
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_MARK(3)
         __syncthreads();     // D(t): gW consumed, partial sums visible
@@ -298,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (t + S >= t_end) break;
         tile(t + S, ks_b, ks_a);
       }
+      }  // !PIPE
     } else {
       // ------------------------------------------------------------------ consumer waves
       const bool slice_owner = !FS || w < 2;  // FS: waves 2, 3 only share Gaussians and keep the barriers
@@ -360,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       };
       // SHARE: Gaussians of one tile, k-step w of this wave, as split fragments in LDS
       const float gl = a.gamma * LOG2E;
-      auto share_fragments = [&]() {  // of the tile whose meta were fetched last
+      auto share_fragments_to = [&](float* fbuf) {  // of the tile whose distances were fetched last
         if (w < NS0 && 2 * w + h < a.nb) {
           const float d = d_m;
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(cen_l + 16 * w + 8 * h);
@@ -368,27 +407,17 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           f16x8 bh, bl, ph, pl;
           rbf_fragments<HALF, HALF>(d, gl, c0, c1, bh, bl, ph, pl);
           const int blk = 2 * w + h;
-          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
-          *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
+          *reinterpret_cast<f16x8*>(fbuf + ((blk * 2 + 0) * 32 + c32) * 4) = bh;
+          *reinterpret_cast<f16x8*>(fbuf + ((blk * 2 + 1) * 32 + c32) * 4) = HALF ? ph : bl;
         }
       };
+      auto share_fragments = [&]() { share_fragments_to(frag_l); };
       // Schedule of one tile (consumer side), between A and B: gW from the rows gathered one tile ago, L1, then the
       // aggregate update interleaved with the gathers of the next tile's rows (they need ~2-3 thousand cycles to
       // arrive under load: issued here they land while the producers run the u GEMM and stage the next tile).
       auto fetch_d = [&](int t) {
         if (SHARE) d_m = pdist[min(t * 32, last_base) + c32];
       };
-      fetch_d(T0);
-      fetch_meta(T0);
-      fill();
-      if (SHARE) share_fragments();
-      fetch_d(T0 + S);
-      fetch_meta(T0 + S);
-      if (SHARE) {
-        __syncthreads();  // first tile's fragments visible
-        __syncthreads();  // ... and consumed
-        share_fragments();
-      }
       // gW of the tile X holds.  It is formed right after the refill's gathers have landed -- between C and D of the
       // PREVIOUS tile, where the consumers would otherwise wait for the producers' u GEMM -- and stored after B.
       f16x2 gwh[8], gwl[8];
@@ -409,6 +438,67 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int p2 = 0; p2 < 8; ++p2) asm volatile("" : "+v"(gwh[p2]), "+v"(gwl[p2]));  // ahead of the MFMAs
       };
+      auto gw_store = [&](char* img) {  // pairs 8q + 4h .. + 3 of this lane's feature: one 8-byte store per plane
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          char* dst = img + gw_row_off(col, 2 * q + h);
+          uint32_t w0, w1;
+          __builtin_memcpy(&w0, &gwh[2 * q], 4);
+          __builtin_memcpy(&w1, &gwh[2 * q + 1], 4);
+          *reinterpret_cast<uint2*>(dst) = uint2{w0, w1};
+          if (!HALF) {
+            __builtin_memcpy(&w0, &gwl[2 * q], 4);
+            __builtin_memcpy(&w1, &gwl[2 * q + 1], 4);
+            *reinterpret_cast<uint2*>(dst + GW_PLANE) = uint2{w0, w1};
+          }
+        }
+      };
+      if constexpr (PIPE) {
+        // the consumers' side of the pipelined form (see PIPE above): per step gW of the NEXT tile into the image the
+        // producers are not reading, the Gaussians of the tile after that into the fragment buffer they are not
+        // reading, then the row gathers of that tile
+        char* img0 = reinterpret_cast<char*>(hid_hi);
+        char* img1 = reinterpret_cast<char*>(gw_img2f);
+        fetch_d(T0);
+        fetch_meta(T0);
+        fill();
+        share_fragments_to(frag_l);    // first tile
+        fetch_d(T0 + S);
+        share_fragments_to(frag_l2);   // second tile
+        form_gw();
+        gw_store(img0);                // gW of the first tile
+        fetch_meta(T0 + S);
+        fill();                        // X <- second tile
+        fetch_meta(T0 + 2 * S);
+        fetch_d(T0 + 2 * S);
+        __syncthreads();  // P0
+        __syncthreads();  // P1
+        FMD_MARK(11)
+        bool odd = false;
+        for (int t = T0; t < t_end; t += S, odd = !odd) {
+          form_gw();                                   // tile t+S
+          gw_store(odd ? img0 : img1);
+          share_fragments_to(odd ? frag_l2 : frag_l);  // tile t+2S
+          FMD_MARK(7)
+          fill();                                      // X <- tile t+2S
+          fetch_meta(t + 3 * S);
+          fetch_d(t + 3 * S);
+          FMD_MARK(5)
+          __syncthreads();  // the step's only barrier
+          FMD_MARK(8)
+        }
+      } else {
+      fetch_d(T0);
+      fetch_meta(T0);
+      fill();
+      if (SHARE) share_fragments();
+      fetch_d(T0 + S);
+      fetch_meta(T0 + S);
+      if (SHARE) {
+        __syncthreads();  // first tile's fragments visible
+        __syncthreads();  // ... and consumed
+        share_fragments();
+      }
       form_gw();  // first tile
       __syncthreads();  // A(first)
       FMD_MARK(11)
@@ -506,19 +596,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         }
         __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {  // pairs 8q + 4h .. + 3 of this lane's feature: one 8-byte store per plane
-          char* dst = reinterpret_cast<char*>(hid_hi) + gw_row_off(col, 2 * q + h);
-          uint32_t w0, w1;
-          __builtin_memcpy(&w0, &gwh[2 * q], 4);
-          __builtin_memcpy(&w1, &gwh[2 * q + 1], 4);
-          *reinterpret_cast<uint2*>(dst) = uint2{w0, w1};
-          if (!HALF) {
-            __builtin_memcpy(&w0, &gwl[2 * q], 4);
-            __builtin_memcpy(&w1, &gwl[2 * q + 1], 4);
-            *reinterpret_cast<uint2*>(dst + GW_PLANE) = uint2{w0, w1};
-          }
-        }
+        gw_store(reinterpret_cast<char*>(hid_hi));
         FMD_MARK(3)
         __syncthreads();  // C(t): gW visible
         FMD_MARK(4)
@@ -532,6 +610,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         __syncthreads();  // A(t+S)
         FMD_MARK(9)
       }
+      }  // !PIPE
     }
   }
   if (NEED_GX1) {
@@ -592,7 +671,10 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
   const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
   const size_t frag = (size_t)a.nb * 1024;
   // shared-Gaussian form when its fragment region fits next to the aggregate (block 0 keeps none)
-  const size_t lds_sh = need ? lds + frag : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag;
+  // (block 0, whole-aggregate mode: the pipelined form -- second fragment buffer, second gW image, second partial sums)
+  const size_t lds_sh = need ? lds + frag
+                             : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag +
+                                   (a.fs ? 0 : frag + (size_t)(4096 + 128) * sizeof(float));
   const bool share = lds_sh <= MAX_LDS_BYTES;
   if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
 #define FMD_ONE(N_, F_, S_, H_, FS_)                                                       \
