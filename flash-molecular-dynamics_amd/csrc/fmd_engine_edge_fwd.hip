@@ -371,13 +371,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           });
         }
         FMD_MARK(1)
-        fetch_meta(t + S);
 #pragma unroll
         for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r];
         asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
         FMD_MARK(2)
         __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(3)
+        fetch_meta(t + S);  // (in the window where the producers write the next tile: the consumers have nothing else there)
         FMD_MARK(4)
         __syncthreads();  // A(t+S)
         FMD_MARK(5)
