@@ -480,9 +480,20 @@ __global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restri
 
 
 // two workgroups (4 waves each) per molecule, each with half of its pair list: forces from dE/dd of the pairs,
-// energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS (float LDS atomics are ordered
-// inside one wave) and the four copies are added in fixed order; the two workgroups then add their halves to
-// the force array that pairs_kernel zeroed: two addends commute, so the result is reproducible.
+// energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS as 64-bit FIXED POINT (2^-32): a
+// scattered ds_add_u64 costs 229 cycles per wave instruction against 768 for ds_add_f32
+// (tools/ubench/lds_atomic_int.hip), integer addition commutes -- any order of the atomics gives the same bits -- and
+// the sum is exact to 2.3e-10 absolute (|dE/dpos| < 2^31).  The four copies are added as integers, converted once; the two
+// workgroups then add their halves to the force array that pairs_kernel zeroed: two addends commute.
+__device__ __forceinline__ unsigned long long fmd_to_fixed(float x) {  // x * 2^32, floor + 32-bit fraction
+  const float fl = floorf(x);
+  const float fr = (x - fl) * 4294967296.0f;  // [0, 2^32]
+  const unsigned lo = fr >= 4294967040.0f ? 0xffffff00u : (unsigned)fr;  // (the largest float below 2^32)
+  return ((unsigned long long)(long long)(int)fl << 32) + lo;
+}
+__device__ __forceinline__ float fmd_from_fixed(unsigned long long q) {
+  return (float)((double)(long long)q * (1.0 / 4294967296.0));
+}
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
                                                      const int64_t* __restrict__ mol_ptr,
                                                      const uint32_t* __restrict__ poi,
@@ -500,9 +511,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t a0 = mol_ptr[m];
   const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
-  float* g = smem + wv * 3 * n;  // this wave's [3n] dE/dpos
+  unsigned long long* gall = reinterpret_cast<unsigned long long*>(smem);
+  unsigned long long* g = gall + wv * 3 * n;  // this wave's [3n] dE/dpos, fixed point
   __shared__ float esum[4];
-  for (int i = tid; i < 12 * n; i += 256) smem[i] = 0.f;
+  for (int i = tid; i < 12 * n; i += 256) gall[i] = 0ull;
   __syncthreads();
   const int np = npairs[m];
   const int np_half = ((np + 15) >> 4) << 3;  // the first workgroup's share (whole 8-entry segments)
@@ -518,9 +530,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
     if (i != ci) {
       if (ci >= 0) {
-        atomicAdd(&g[3 * ci], cx);
-        atomicAdd(&g[3 * ci + 1], cy);
-        atomicAdd(&g[3 * ci + 2], cz);
+        atomicAdd(&g[3 * ci], fmd_to_fixed(cx));
+        atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy));
+        atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz));
       }
       ci = i;
       cx = cy = cz = 0.f;
@@ -532,18 +544,18 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
       const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
       const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
       const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
-      atomicAdd(&g[3 * j], dx);
-      atomicAdd(&g[3 * j + 1], dy);
-      atomicAdd(&g[3 * j + 2], dz);
+      atomicAdd(&g[3 * j], fmd_to_fixed(dx));
+      atomicAdd(&g[3 * j + 1], fmd_to_fixed(dy));
+      atomicAdd(&g[3 * j + 2], fmd_to_fixed(dz));
       cx -= dx;
       cy -= dy;
       cz -= dz;
     }
   }
   if (ci >= 0) {
-    atomicAdd(&g[3 * ci], cx);
-    atomicAdd(&g[3 * ci + 1], cy);
-    atomicAdd(&g[3 * ci + 2], cz);
+    atomicAdd(&g[3 * ci], fmd_to_fixed(cx));
+    atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy));
+    atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz));
   }
   if (half == 0) {
     float e = 0.f;
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   }
   __syncthreads();
   for (int i = tid; i < 3 * n; i += 256)
-    unsafeAtomicAdd(&forces[3 * a0 + i], -(((smem[i] + smem[3 * n + i]) + smem[6 * n + i]) + smem[9 * n + i]));
+    unsafeAtomicAdd(&forces[3 * a0 + i], -fmd_from_fixed(((gall[i] + gall[3 * n + i]) + gall[6 * n + i]) + gall[9 * n + i]));
   if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
   // the call's status words from pairs_kernel's per-molecule reports (one wave of the first workgroup; a bead-bound
   // violation outranks a capacity overflow)
@@ -613,7 +625,7 @@ int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x
 }
 
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s) {
-  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(float), s>>>(
+  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(unsigned long long), s>>>(
       a.pos, a.mol_ptr, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
       a.report, a.status);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
