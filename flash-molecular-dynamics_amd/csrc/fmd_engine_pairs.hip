@@ -24,6 +24,9 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
   // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
   // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
+  // squared distances as separately rounded fp32 products and sums in the oracle's order: plain operators under
+  // contract(off) (the __f*_rn intrinsics are header functions that keep contract = fast and were fused into v_fma_f32)
+#pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
   __syncthreads();
   auto dist2 = [&](int i, int j) {
-    const float dx = __fsub_rn(sx[j], sx[i]), dy = __fsub_rn(sy[j], sy[i]), dz = __fsub_rn(sz[j], sz[i]);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    const float dx = sx[j] - sx[i], dy = sy[j] - sy[i], dz = sz[j] - sz[i];
+    return (dx * dx + dy * dy) + dz * dz;
   };
   // ---- pass 1: the hit masks and row counts.  A lane keeps its candidates j = 64 c + lane in registers (beads
   //      beyond the molecule sit at 1e30: their d2 is +inf and never a hit), a wave takes one centre row at a time.
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         if (c >= c_first && c < NC) {
-          const float dx = __fsub_rn(px[c], xi), dy = __fsub_rn(py[c], yi), dz = __fsub_rn(pz[c], zi);
-          const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+          const float dx = px[c] - xi, dy = py[c] - yi, dz = pz[c] - zi;
+          const float d2 = (dx * dx + dy * dy) + dz * dz;
           const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2);
           mlo = lane == c ? (unsigned)mk : mlo;
           mhi = lane == c ? (unsigned)(mk >> 32) : mhi;

@@ -1,7 +1,7 @@
 // A1: radius graph inside each molecule (replaces torch_cluster.radius_graph as called from the
 // reference's neighbor_list/torch_impl.py:216-224).  One wave per centre bead: the wave sweeps the
 // molecule's beads 64 at a time from LDS, the strict test d2 < rc2 is made with unfused fp32
-// (__fmul_rn/__fadd_rn) so the edge set is bit-identical to the CPU oracle, and hits are compacted
+// (contract(off): separately rounded products and sums) so the edge set is bit-identical to the CPU oracle, and hits are compacted
 // with a ballot so rows come out sorted by neighbour index.
 #include "fmd_common.h"
 
@@ -12,8 +12,11 @@ constexpr int NB_TILE = 1024;         // beads staged in LDS per sweep step
 
 __device__ __forceinline__ bool within(float xi, float yi, float zi, float xj, float yj, float zj,
                                        float rc2) {
-  float dx = __fsub_rn(xj, xi), dy = __fsub_rn(yj, yi), dz = __fsub_rn(zj, zi);
-  float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  // plain operators under contract(off): the __fmul_rn / __fadd_rn intrinsics are header functions whose * and + keep
+  // the translation unit's default (contract = fast) and were fused into v_fma_f32 after inlining
+#pragma clang fp contract(off)
+  float dx = xj - xi, dy = yj - yi, dz = zj - zi;
+  float d2 = (dx * dx + dy * dy) + dz * dz;
   return d2 < rc2;
 }
 
