@@ -63,6 +63,36 @@ def test_radius_graph_cutoff_boundary_is_strict(K):
     assert (0, 1) not in pairs and (0, 3) not in pairs and (0, 2) in pairs
 
 
+def test_radius_graph_pairs_within_an_ulp_of_the_cutoff(K, golden_dir):
+    """480 beads on a sphere of radius 5 (1 +- 2e-7) around bead 0: hundreds of squared distances within one or two
+    ulps of rc^2, where a fused d2 = dx dx + fma(dz, dz, dy dy) and the separately rounded (dx dx + dy dy) + dz dz of
+    the oracle disagree.  The operator's edge list and the engine's pair count must both match the oracle exactly
+    (the kernels had been contracted once: the __fmul_rn / __fadd_rn intrinsics do not stop it)."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(11)
+    n = 480
+    u = torch.randn(n, 3, generator=g, dtype=torch.float64)
+    u = u / u.norm(dim=1, keepdim=True)
+    r = 5.0 * (1.0 + 2e-7 * (2 * torch.rand(n, 1, generator=g, dtype=torch.float64) - 1))
+    pos = (u * r).float()
+    pos[0] = 0.0
+    ptr = torch.tensor([0, n])
+    src, dst = so.radius_graph(pos, ptr, 5.0)
+    d2 = (pos[1:] ** 2).sum(1)
+    near = int(((d2 - 25.0).abs() <= 4e-6).sum())
+    inside = int((src == 0).sum())
+    assert near > 200 and 50 < inside < n - 50   # the case is what it claims to be
+    ei = K.radius_graph(pos.to(DEV), 5.0, None, ptr_=ptr.to(DEV), max_beads_per_mol=n).cpu()
+    assert ei.shape == (2, src.numel()) and torch.equal(ei[0], src) and torch.equal(ei[1], dst)
+    params = so.params_from_npz(os.path.join(golden_dir, "weights_L3_R50.npz"))
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    types = torch.randint(1, 20, (n,), generator=g)
+    eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), n)
+    assert int(eng.status[0]) == 0 and int(eng.status[2]) == src.numel() // 2
+
+
 # ---------------------------------------------------------------------------------------- A2
 def test_distance_rbf_forward_and_backward(K):
     pos, _, ptr, src, dst = _graph()
