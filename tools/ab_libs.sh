@@ -11,7 +11,7 @@ for pass in 1 2; do
 import json, sys
 d = json.load(open("/tmp/ab.json"))
 k = d["kernel_ms_per_launch"]
-print(sys.argv[1], round(d["value"]), "fwd", k["edge_fwd_kernel"], "bwd", k["edge_bwd_kernel"], "node fwd/out/bwd", k["node_fwd_kernel"], k["node_out_kernel"], k["node_bwd_kernel"])
+print(sys.argv[1], round(d["value"]), "fwd", k["edge_fwd_kernel"], "bwd", k["edge_bwd_kernel"], "node fwd/out/bwd", k["node_fwd_kernel"], k["node_out_kernel"], k["node_bwd_kernel"], "pairs/finish", k["pairs_kernel"], k["finish_kernel"])
 PY
   done
 done
