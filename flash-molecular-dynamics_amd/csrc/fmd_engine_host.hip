@@ -114,8 +114,11 @@ int device_cus() {
 }
 int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
   if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
+  // as many workgroups per molecule as fit the chip in ONE round (floor, not ceil: 100 molecules x 3 would take a second
+  // round for 44 workgroups -- 0.67 of a molecule's tiles per CU against 0.5 with x 2 -- and only a launch of one round
+  // gets the balanced work items)
   const int cus = device_cus();
-  int64_t s = n_mol > 0 ? (cus + n_mol - 1) / n_mol : 1;
+  int64_t s = n_mol > 0 ? cus / n_mol : 1;
   if (s < 1) s = 1;
   if (s > MAX_SPLIT) s = MAX_SPLIT;
   return (int)s;
