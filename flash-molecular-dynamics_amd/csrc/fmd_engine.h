@@ -158,7 +158,9 @@ struct SchedArgs {
   const int32_t* npairs;
   const int64_t* mol_ptr;
   int n_mol, n_split;
-  int balanced;            // 1: even out the tiles over the workgroups (one wave of workgroups, n_mol <= 256)
+  int balanced;            // 1: even out the tiles over the workgroups (one wave of workgroups, n_mol <= 256);
+                           // 2: chained -- n_wg workgroups (<= 256) take consecutive chunks of the global tile sequence
+  int n_wg;                // chained form: workgroups of the pair-kernel launch (grid (1, n_wg))
   int fs;
   int64_t n_nodes;
   int* items;

@@ -298,8 +298,13 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
   const int split = fs ? 2 : resolve_split(desc, n_mol);  // FS: the two feature halves
-  if ((int64_t)(split + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
-  const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, split);
+  // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
+  const int cus = device_cus();
+  const bool chain = !fs && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
+  const int n_slabs = chain ? 2 : split;                       // regular slabs the node kernels add
+  const int64_t pair_wgs = chain ? cus : n_mol;                // grid.y of the pair kernels
+  if ((int64_t)(n_slabs + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
+  const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, n_slabs);
   const PackLayout PL = pack_layout(desc);
   const float* pk = reinterpret_cast<const float*>(packed_dev);
 
@@ -319,7 +324,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     // the pair kernels' work items (sched_body in fmd_engine_pairs.hip): balanced when the split is left to the library
     // and the whole launch is one round of workgroups; a caller-given n_split keeps the static tile interleave
     sa.npairs = ws.npairs; sa.mol_ptr = mol_ptr; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
-    sa.balanced = (!fs && n_mol >= 2 && n_mol <= 256 && n_mol * split <= device_cus() && desc->n_split == 0) ? 1 : 0;
+    sa.balanced = chain ? 2 : (!fs && n_mol >= 2 && n_mol <= 256 && n_mol * split <= cus && desc->n_split == 0) ? 1 : 0;
+    sa.n_wg = (int)pair_wgs;
     sa.n_nodes = n_nodes; sa.items = ws.items; sa.extra_row = ws.extra_row;
     ev_begin();
     rc = launch_pairs(pa, n_mol, s);
@@ -330,7 +336,6 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const bool half = desc->precision == FMD_PREC_W16A16;
   const int64_t n_tiles = (n_nodes + 31) / 32;
   // node kernels: one workgroup per CU walks 32-row tiles (the kernels keep their operands in registers)
-  const int64_t cus = device_cus();
   const unsigned res_grid = (unsigned)(n_tiles < cus ? n_tiles : cus);
   const int64_t slab_stride = n_nodes * F;
 
@@ -351,8 +356,8 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
     ea.dbg = (ea.stamps || g_stamp_block == -2) ? g_stamp_dbg : 0;   // block -2: the switches apply to every launch
 #endif
-    if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, n_mol, s);
-    return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, n_mol, s);
+    if (fwd) return launch_edge_fwd(ea, desc->num_rbf, half, pair_wgs, s);
+    return launch_edge_bwd(ea, desc->num_rbf, half, /*need_gx1=*/l > 0, /*first=*/l == L - 1, pair_wgs, s);
   };
 
   // ---------------- forward
@@ -364,7 +369,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     } else {
       const BlockOff q = block_off(PL, l - 1);
       NodeFwdArgs na;
-      na.x = ws.x; na.slabs = ws.slabs; na.slab_stride = slab_stride; na.n_slabs = split; na.extra_row = ws.extra_row;
+      na.x = ws.x; na.slabs = ws.slabs; na.slab_stride = slab_stride; na.n_slabs = n_slabs; na.extra_row = ws.extra_row;
       na.l1 = pk + o.l1; na.x1_out = ws.x1[l]; na.n_nodes = n_nodes;
       na.l2 = pk + q.l2; na.b2 = pk + q.b2; na.l3 = pk + q.l3; na.b3 = pk + q.b3; na.t_out = ws.t[l - 1];
       rc = launch_node_fwd(na, res_grid, s);
@@ -379,7 +384,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   {
     const BlockOff q = block_off(PL, L - 1);
     NodeOutArgs oa;
-    oa.x = ws.x; oa.slabs = ws.slabs; oa.slab_stride = slab_stride; oa.n_slabs = split; oa.extra_row = ws.extra_row;
+    oa.x = ws.x; oa.slabs = ws.slabs; oa.slab_stride = slab_stride; oa.n_slabs = n_slabs; oa.extra_row = ws.extra_row;
     oa.l2 = pk + q.l2; oa.b2 = pk + q.b2; oa.l3 = pk + q.l3; oa.b3 = pk + q.b3; oa.t_out = ws.t[L - 1];
     for (int k = 0; k < 3; ++k) {
       const int kk = k < desc->num_out ? k : desc->num_out - 1;
@@ -396,7 +401,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   for (int l = L - 1; l >= 0; --l) {
     const BlockOff o = block_off(PL, l);
     NodeBwdArgs ba;
-    ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = split; ba.extra_row = ws.extra_row;
+    ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = n_slabs; ba.extra_row = ws.extra_row;
     ba.t = ws.t[l]; ba.l3t = pk + o.l3t; ba.l2t = pk + o.l2t; ba.gagg = ws.gagg; ba.n_nodes = n_nodes;
     ba.l1t = l == L - 1 ? nullptr : pk + block_off(PL, l + 1).l1t;
     ev_begin();

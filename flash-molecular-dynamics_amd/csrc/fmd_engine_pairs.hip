@@ -378,6 +378,72 @@ __device__ __forceinline__ void sched_body(const SchedArgs& a) {
     return;
   }
   // (all global reads up front, one round trip: the lookup's traffic runs beside this workgroup)
+  if (a.balanced == 2) {
+    // Chained form (129..255 molecules: one workgroup per molecule would leave CUs idle, two would need a second
+    // round).  Workgroup w of n_wg takes tiles [w q, (w + 1) q) of the molecules' tiles laid end to end, q = ceil(T /
+    // n_wg): with q below the smallest and at least half the largest molecule a chunk touches at most two molecules
+    // and a molecule at most three chunks -- piece 0 and 1 go to slabs 0 and 1 (every molecule has both), piece 2 to an
+    // extra slab.  Batches that do not satisfy the two conditions fall back to halves: the first half of molecule m
+    // on workgroup m, the second on workgroup B + m while those last, else on workgroup m as well.
+    __shared__ int tt[256], pp[257], a0c[256], nbc[256], x3[257];
+    __shared__ int tmin_s, tmax_s;
+    const int G = a.n_wg;
+    const int t_c = tid < B ? (a.npairs[tid] + 31) >> 5 : 0;
+    tt[tid] = t_c;
+    a0c[tid] = tid < B ? (int)a.mol_ptr[tid] : 0;
+    nbc[tid] = tid < B ? (int)(a.mol_ptr[tid + 1] - a.mol_ptr[tid]) : 0;
+    if (tid == 0) { tmin_s = 0x7fffffff; tmax_s = 0; }
+    __syncthreads();
+    if (tid < B) { atomicMin(&tmin_s, t_c); atomicMax(&tmax_s, t_c); }
+    if (tid == 0) {  // exclusive prefix of the tile counts (B <= 256: a serial pass over LDS)
+      int acc = 0;
+      for (int m = 0; m < B; ++m) { pp[m] = acc; acc += tt[m]; }
+      pp[B] = acc;
+    }
+    __syncthreads();
+    const int T = pp[B], q = max(1, (T + G - 1) / G);
+    const bool chain = T > 0 && q < tmin_s && tmax_s <= 2 * q;
+    if (chain) {
+      // molecules with a third piece and the rows of their extra slabs
+      const bool three = tid < B && (pp[tid] + t_c - 1) / q - pp[tid] / q == 2;
+      x3[tid] = three ? nbc[tid] : 0;
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0;
+        for (int m = 0; m < B; ++m) { const int v = x3[m]; x3[m] = acc; acc += v; }
+      }
+      __syncthreads();
+      auto dst = [&](int m, int k) { return k < 2 ? k * N + a0c[m] : 2 * N + x3[m]; };
+      if (tid < G) {
+        const int lo = tid * q, hi = min(lo + q, T);
+        if (lo >= T) {
+          put(tid, 0, -1, 0, 0, 1, 0);
+          put(tid, 1, -1, 0, 0, 1, 0);
+        } else {
+          int m0 = 0;  // the molecule that holds global tile lo: the last m with pp[m] <= lo
+          for (int step = 128; step > 0; step >>= 1)
+            if (m0 + step < B && pp[m0 + step] <= lo) m0 += step;
+          put(tid, 0, m0, lo - pp[m0], min(hi, pp[m0 + 1]) - pp[m0], 1, dst(m0, tid - pp[m0] / q));
+          if (hi > pp[m0 + 1]) put(tid, 1, m0 + 1, 0, hi - pp[m0 + 1], 1, dst(m0 + 1, 0));
+          else put(tid, 1, -1, 0, 0, 1, 0);
+        }
+      }
+      if (three)
+        for (int r = 0; r < nbc[tid]; ++r) a.extra_row[a0c[tid] + r] = 2 * N + x3[tid] + r;
+    } else if (tid < G) {
+      if (tid < B) {
+        const int hf = (t_c + 1) >> 1;
+        put(tid, 0, tid, 0, hf, 1, a0c[tid]);
+        if (tid + B < G) put(tid, 1, -1, 0, 0, 1, 0);
+        else put(tid, 1, tid, hf, t_c, 1, N + a0c[tid]);
+      } else {
+        const int m = tid - B, hf = (tt[m] + 1) >> 1;
+        put(tid, 0, m, hf, tt[m], 1, N + a0c[m]);
+        put(tid, 1, -1, 0, 0, 1, 0);
+      }
+    }
+    return;
+  }
   const int t_me = tid < B ? (a.npairs[tid] + 31) >> 5 : 0;
   const int a0_me = tid < B ? (int)a.mol_ptr[tid] : 0, n_me = tid < B ? (int)(a.mol_ptr[tid + 1] - a.mol_ptr[tid]) : 0;
   __shared__ int a0_m[256], n_m[256];

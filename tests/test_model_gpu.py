@@ -492,6 +492,48 @@ def test_fused_engine_random_ragged_batches(params):
     assert re < 1e-4 and rf < 1e-4
 
 
+@pytest.mark.parametrize("shape", ["chain160", "halves200"])
+def test_chained_schedule_between_half_and_all_cus(params, shape):
+    """129..255 molecules: the pair kernels launch one workgroup per CU and take consecutive chunks of all molecules'
+    tiles laid end to end (chain160: 160 molecules of 150 beads, every molecule spans two or three chunks, the third piece
+    goes through the extra slab); a batch whose sizes do not allow that falls back to halves (halves200: 200 molecules of
+    20..120 beads).  Checked against the static items (n_split given) and, for two molecules, the fp64 oracle."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(9)
+    if shape == "chain160":
+        sizes = [150] * 160
+    else:
+        sizes = [int(v) for v in torch.randint(20, 121, (200,), generator=g)]
+    mols = []
+    for n in sizes:
+        x = torch.randn(n, 3, generator=g)
+        mols.append(x / x.norm(dim=1, keepdim=True) * 7.2 * (n / 269.0) ** (1 / 3) * torch.rand(n, 1, generator=g) ** (1 / 3))
+    pos = torch.cat(mols)
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    types = torch.randint(1, 20, (pos.shape[0],), generator=g)
+    model = S.model_from_params(params).to(DEV)
+    auto, sta = engine.FusedSchNetEngine(model), engine.FusedSchNetEngine(model, n_split=2)
+    e_a, f_a = auto.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), max(sizes))
+    e_s, f_s = sta.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), max(sizes))
+    assert int(auto.status[0]) == 0 and int(sta.status[0]) == 0 and int(auto.status[2]) == int(sta.status[2])
+    re = float((e_a - e_s).abs().max() / e_s.abs().max())
+    rf = float((f_a - f_s).norm() / f_s.norm())
+    print(f"{shape}: chained vs static items, energy {re:.2e} forces {rf:.2e}")
+    assert re < 2e-5 and rf < 2e-5
+    e_2, f_2 = auto.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), max(sizes))
+    assert torch.equal(e_2, e_a) and torch.equal(f_2, f_a)
+    for m in (0, len(sizes) - 1):
+        sl = slice(int(ptr[m]), int(ptr[m + 1]))
+        e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sl].double(), types[sl],
+                                           torch.tensor([0, sizes[m]]))
+        _, r_f = _relerr(e_a[m:m + 1], f_a[sl], e_o.numpy(), f_o.numpy())
+        # (a single molecule's energy can sit near zero: its error is measured against the batch's energy scale)
+        r_e = abs(float(e_a[m]) - float(e_o[0])) / float(e_a.abs().max())
+        assert r_e < 1e-4 and r_f < 1e-4, (m, r_e, r_f)
+
+
 @pytest.mark.parametrize("shape", ["one_large", "b256"])
 def test_balanced_schedule_extreme_batches(params, shape):
     """The balanced work items where the pairing is lopsided: one 269-bead molecule among 127 of 8..14 beads (the
