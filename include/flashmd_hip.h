@@ -181,9 +181,11 @@ typedef struct fmd_schnet_desc {
   int32_t out_width[4];  /* widths after each output linear, last = 1 */
   int32_t embedding_size;
   int32_t precision;
-  int32_t n_split;       /* workgroups per molecule in the pair kernels; 0 = auto (CUs / n_mol, 1..32; when that fills
-                            the chip in one round, tiles of large molecules are handed to the workgroups of small ones
-                            so that every workgroup walks about the same number), > 0 = fixed static interleave */
+  int32_t n_split;       /* workgroups per molecule in the pair kernels; 0 = auto: floor(CUs / n_mol) in 1..32, one round
+                            of workgroups for up to CUs molecules, with the tiles of large molecules handed to the
+                            workgroups of small ones so that every workgroup walks about the same number (more than
+                            CUs / 2 but fewer than CUs molecules: one workgroup per CU over equal chunks of all tiles);
+                            > 0 = fixed static interleave */
   float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
   float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
 } fmd_schnet_desc;
