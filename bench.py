@@ -1,23 +1,33 @@
 """Benchmark of the hot path: timestep*mol/s of CGSchNet Langevin dynamics on synthetic 1ENH-shaped
 batches (BASELINE.json metric), one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step is one BAOAB Langevin timestep of the rank's batch: fused elementwise half, the fused HIP
-force engine (neighbour pairs -> SchNet energy -> forces), second half-kick.  Inputs are resident in
-HBM before the timed region.  Replicas shard across ranks with no collective in the data path (weak
-scaling: every rank owns --batch molecules).  Rank 0 prints ONE JSON line.
+With --gpus N > 1 and no RANK in the environment the script starts its own ranks:
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+bench.py <same arguments>` as a CHILD process (never an exec), relays its output and exits with its code; launched
+by torch.distributed.run directly (RANK set) it is one of the ranks.
+
+A step is one BAOAB Langevin timestep of the rank's batch: fused elementwise half, the fused HIP force engine
+(neighbour pairs -> SchNet energy -> forces) reached through the reference-shaped entry `GradientsOut(model)(batch)`
+(reference models/gradients.py:226-290), second half-kick.  Inputs are resident in HBM before the timed region.
+Replicas shard across ranks with no collective in the data path (weak scaling: every rank owns --batch molecules).
+Rank 0 prints ONE JSON line.  The headline is BASELINE configs[1] (fp32); at N = 1 the default run appends a short
+W16A16 leg (BASELINE configs[2], the configuration the reference's published 2861 is quoted on) as the key `w16a16`.
 
   --pt   BASELINE configs[4]: parallel tempering, one beta per rank (geometric ladder down from 1.67, reference
-         examples/parallel_tempering.yaml:19), an exchange attempt every --exchange-interval steps over
-         point-to-point RCCL send/recv; with --gpus 1 the --pt-betas temperatures share the batch and the swap is
-         the in-batch HIP kernel (the reference's own layout).  The line then also carries exchange time and the
-         acceptance per temperature pair.
+         examples/parallel_tempering.yaml:19), exchange attempts every --exchange-interval steps over point-to-point
+         RCCL send/recv -- or, when --steps is shorter than two intervals, after steps//3 and 2*steps//3, so that the
+         timed region always holds one even-phase and one odd-phase attempt; with --gpus 1 the --pt-betas
+         temperatures share the batch and the swap is the in-batch HIP kernel (the reference's own layout).  The line
+         then also carries exchange time, bytes moved and the acceptance per temperature pair.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,9 +44,25 @@ PEAK_F16_MFMA_TFLOPS = 16 * PEAK_F32_MFMA_TFLOPS  # same table: fp32 matrix rate
 # The pair kernels compute fp32-grade products as three f16 MFMA products of split operands
 # (hi.hi + hi.lo + lo.hi, fp32 accumulate): the roof for ALGORITHMIC flops is a third of the f16 peak.
 PEAK_SPLIT3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
+N_REGIONS = 5        # back-to-back repeats of the timed region when --steps < 200 (the first one is `value`)
+N_PROFILE = 5        # untimed steps with every kernel bracketed (the first is dropped)
+
+PRECISIONS = {
+    "f32": dict(dtype="f32", peak=PEAK_SPLIT3_TFLOPS, cfg="Langevin fp32 (BASELINE configs[1])",
+                arith="fp32 storage and accumulation; filter-network and node GEMMs as split-operand f16 MFMA: "
+                      "x = hi + lo with hi = f16(x) and an UNSCALED low word lo = f16(x - hi) for operands of bounded "
+                      "magnitude (weights, Gaussians, C*tanh; all three products on one fp32 accumulator), the scaled "
+                      "form lo = f16((x - hi) * 2048) on two accumulators for the unbounded gW operand; "
+                      "error 2e-7 per contraction = fp32 MFMA grade",
+                note="dense f16 MFMA peak (16 x 157.3) / 3 products per fp32-grade product; "
+                     "the exact-fp32 MFMA peak is 157.3"),
+    "w16a16": dict(dtype="f16", peak=PEAK_F16_MFMA_TFLOPS, cfg="W16A16 (BASELINE configs[2])",
+                   arith="filter and output networks: fp16 operands, fp32 accumulation (reference "
+                         "W16A16 mode); node linears fp32-grade", note="dense f16 MFMA peak (16 x 157.3)"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
@@ -46,8 +72,11 @@ def parse():
     ap.add_argument("--num-rbf", type=int, default=50)
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--precision", default="f32", choices=["f32", "w16a16"],
-                    help="f32 = BASELINE configs[1] (default, the judged line); w16a16 = configs[2]")
+                    help="f32 = BASELINE configs[1] (default, the judged line); w16a16 = configs[2] as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-w16a16-leg", action="store_true",
+                    help="skip the short W16A16 leg the default single-GPU fp32 run appends")
+    ap.add_argument("--w16a16-steps", type=int, default=20)
     ap.add_argument("--reset-every", type=int, default=0,
                     help="restore positions, velocities and forces of the start of the timed region every this many "
                          "steps (inside the timed region): a long run then repeats the specified workload instead of "
@@ -59,13 +88,53 @@ def parse():
     ap.add_argument("--pt", action="store_true", help="parallel tempering (BASELINE configs[4])")
     ap.add_argument("--exchange-interval", type=int, default=100, help="reference examples/parallel_tempering.yaml:11")
     ap.add_argument("--pt-betas", type=int, default=8, help="temperatures in the batch when --pt runs on one GPU")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launching the ranks
+# ------------------------------------------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_argv(n_gpus: int, port: int, script_args):
+    """The command `python bench.py --gpus N ...` turns itself into (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *script_args]
+
+
+def needs_self_launch(args, environ) -> bool:
+    return args.gpus > 1 and "RANK" not in environ
+
+
+def self_launch(args) -> int:
+    """Start the ranks as a child process and return its exit code.  Nothing in this process has touched the GPU."""
+    cmd = launcher_argv(args.gpus, free_port(), sys.argv[1:])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL on this driver: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def beta_ladder(n):
     """examples/parallel_tempering.yaml:19 is [1.67, 1.42, 1.16]: a geometric ladder (ratio 0.8334) continued to n"""
     r = (1.16 / 1.67) ** 0.5
     return [1.67 * r ** k for k in range(n)]
+
+
+def attempt_steps(steps: int, interval: int):
+    """Step counts (1-based, inside one timed region) after which an exchange is attempted: every `interval` steps as
+    the reference does (simulation/parallel_tempering.py:349-366); a region shorter than two intervals attempts after
+    steps//3 and 2*steps//3 instead, so that it always times one even- and one odd-phase attempt."""
+    if steps >= 2 * interval:
+        return list(range(interval, steps + 1, interval))
+    if steps < 2:
+        return [steps] if steps == 1 else []
+    a = max(1, steps // 3)
+    return [a, max(a + 1, (2 * steps) // 3)]
 
 
 class HipEvents:
@@ -127,11 +196,170 @@ def cpu_baseline(model, args):
                                           "the size of BASELINE configs[0]"}}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# one precision = one leg: engine, simulation, kernel profile, timed regions
+# ------------------------------------------------------------------------------------------------------------------
+class Leg:
+    def __init__(self, S, engine, simulate, model, precision, state, args, barrier):
+        """state = (pos, types, ptr, masses, beta) on the device"""
+        self.args, self.barrier, self.precision = args, barrier, precision
+        pos, types, ptr, masses, beta = state
+        self.eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")), precision=precision)
+        self.names = self.eng.kernel_names()
+        self.nk = len(self.names)
+        # the reference-shaped entry point: GradientsOut(model)(batch) finds the engine on the model; one collated
+        # batch whose positions are updated, as the reference's simulation keeps one AtomicData
+        # (simulation/base.py:991-1020)
+        self.model, self.go = model, S.GradientsOut(model).eval()
+        self.batch_obj = S.Batch(pos, types, ptr, max_beads_per_mol=args.beads)
+        self.types, self.ptr = types, ptr
+        self.events_for_next = None   # callable -> ctypes event array for the next force evaluation, or None
+        model._engine = self.eng
+        self.sim = simulate.LangevinSimulation(self.force_via_gradients_out, pos, masses, beta, args.beads,
+                                               dt=0.004, friction=1.0)
+
+    def force_via_gradients_out(self, x):
+        if self.events_for_next is not None:
+            self.eng.next_events = self.events_for_next()
+        self.model._engine = self.eng
+        self.batch_obj.pos, self.batch_obj.out = x, {}
+        d = self.go(self.batch_obj)
+        return d.out["SchNet"]["energy"], d.out["SchNet"]["forces"]
+
+    def force_direct(self, x):
+        return self.eng.energy_forces(x, self.types, self.ptr, self.args.beads)
+
+    def profile(self):
+        """N_PROFILE untimed steps with every kernel bracketed (plus the integrator's kernels through torch events on
+        the same stream): the per-kernel table, and which kernel dominates."""
+        nk, sim = self.nk, self.sim
+        ev = HipEvents(2 * nk * N_PROFILE)
+        te = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(N_PROFILE)]
+        step = {"i": 0}
+        self.events_for_next = lambda: (ctypes.c_void_p * (2 * nk)).from_buffer(
+            ev.ev, step["i"] * 2 * nk * ctypes.sizeof(ctypes.c_void_p))
+        from flashmd_amd import simulate as sm
+        for i in range(N_PROFILE):   # the BAOAB step spelled out, so that its three pieces can be bracketed
+            step["i"] = i
+            te[i][0].record()
+            sim.noise.normal_(generator=sim.rng)
+            sm.langevin_pre(sim.x, sim.v, sim.f, sim.masses, sim.beta_node, sim.noise, sim.dt, sim.friction)
+            te[i][1].record()
+            sim.energy, sim.f = sim.force_fn(sim.x)
+            te[i][2].record()
+            sm.langevin_post(sim.v, sim.f, sim.masses, sim.dt)
+            te[i][3].record()
+        self.events_for_next = None
+        torch.cuda.synchronize()
+        per = {}
+        for k, name in enumerate(self.names):
+            per.setdefault(name, []).extend(ev.elapsed_ms((i * nk + k) * 2, (i * nk + k) * 2 + 1)
+                                            for i in range(1, N_PROFILE))
+        self.launches = {n: len(v) / (N_PROFILE - 1) for n, v in per.items()}
+        self.prof_ms = {n: sum(v) / len(v) for n, v in per.items()}
+        self.integrator_ms = sum(te[i][0].elapsed_time(te[i][1]) + te[i][2].elapsed_time(te[i][3])
+                                 for i in range(1, N_PROFILE)) / (N_PROFILE - 1)
+        self.dom = max(self.prof_ms, key=lambda n: self.prof_ms[n] * self.launches[n])
+        self.dom_slots = [k for k, name in enumerate(self.names) if name == self.dom]
+
+    def settle(self, seconds):
+        """untimed force evaluations at the CURRENT positions (nothing is integrated: the synthetic system is not
+        stationary -- its pair count falls by 0.8 % in 500 steps -- so steps here would hand the timed region a
+        lighter workload)"""
+        n, t_s = 0, time.perf_counter()
+        while time.perf_counter() - t_s < seconds:
+            for _ in range(20):
+                self.sim.force_fn(self.sim.x)
+            torch.cuda.synchronize()
+            n += 20
+        return n
+
+    def timed_region(self, steps, events, exchange=None, attempts=(), reset_every=0, tenth=0):
+        """EXACTLY `steps` timesteps between barrier + synchronize brackets; the dominant kernel's launches are
+        bracketed by `events` (2 * len(dom_slots) * steps handles, reused from region to region).  Returns wall
+        seconds of this rank and the exchange / sustained-rate bookkeeping."""
+        sim, nk, n_dom = self.sim, self.nk, len(self.dom_slots)
+        step = {"i": -1}
+
+        def ev_next():
+            i = step["i"]
+            if i < 0:
+                return None
+            arr = (ctypes.c_void_p * (2 * nk))()
+            for j, slot in enumerate(self.dom_slots):
+                arr[2 * slot], arr[2 * slot + 1] = events.ev[(i * n_dom + j) * 2], events.ev[(i * n_dom + j) * 2 + 1]
+            step["i"] = -1   # one evaluation per step carries events (an exchange's re-evaluation does not)
+            return arr
+
+        self.events_for_next = ev_next
+        marks, t_exchange, n_exchange = {}, 0.0, 0
+        attempts = set(attempts)
+        if reset_every:
+            x0, v0, f0, e0 = sim.x.clone(), sim.v.clone(), sim.f.clone(), sim.energy.clone()
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step["i"] = i
+            sim.timestep()
+            if reset_every and (i + 1) % reset_every == 0:   # (three device copies of 0.4 MB, timed)
+                sim.x.copy_(x0); sim.v.copy_(v0); sim.f.copy_(f0); sim.energy.copy_(e0)
+            if exchange is not None and (i + 1) in attempts:
+                step["i"] = -1
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                exchange(sim)
+                torch.cuda.synchronize()
+                t_exchange += time.perf_counter() - te
+                n_exchange += 1
+            if tenth and i + 1 in (tenth, steps - tenth):
+                torch.cuda.synchronize()
+                marks[i + 1] = time.perf_counter() - t0
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        self.events_for_next = None
+        return elapsed, marks, t_exchange, n_exchange
+
+    def dominant_ms(self, events, steps):
+        n_dom = len(self.dom_slots)
+        v = [events.elapsed_ms((i * n_dom + j) * 2, (i * n_dom + j) * 2 + 1) for i in range(steps) for j in range(n_dom)]
+        return sum(v) / len(v)
+
+
+def kernel_table(leg, dom_ms, ms_per_step):
+    """Per-kernel milliseconds of one step.  The dominant kernel: HIP events over the timed region.  The others were
+    measured with EVERY launch bracketed (an event record drains the stream around it, a few microseconds per launch), so
+    their sum overshoots; they are scaled by one common factor so that the table adds up to the measured step."""
+    raw = dict(leg.prof_ms)
+    raw[leg.dom] = dom_ms
+    per_step_raw = {n: raw[n] * leg.launches[n] for n in raw}
+    per_step_raw["integrator_and_noise"] = leg.integrator_ms
+    others = sum(v for n, v in per_step_raw.items() if n != leg.dom)
+    room = ms_per_step - per_step_raw[leg.dom]
+    scale = min(1.0, room / others) if others > 0 and room > 0 else 1.0
+    per_step = {n: (v if n == leg.dom else v * scale) for n, v in per_step_raw.items()}
+    return raw, per_step_raw, per_step, scale
+
+
 def main():
     args = parse()
+    if needs_self_launch(args, os.environ):
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FMD_BENCH_LAUNCH_CHECK") == "1":
+        # plumbing check of the launch path alone (tests/test_abi_and_host.py, no GPU needed): the ranks rendezvous
+        # over gloo, agree on who is there, rank 0 reports -- nothing is measured
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": int(t.item()),
+                              "gpus_arg": args.gpus}), flush=True)
+        dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs the GPU (the HIP path has no CPU fallback)"
     # FMD_BENCH_REHEARSE=1: rehearsal of the N > 1 plumbing on a box with fewer GPUs than ranks (ranks share
     # devices, gloo instead of RCCL); never used for a reported number
@@ -140,6 +368,7 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
@@ -161,9 +390,6 @@ def main():
             if n_.endswith("bias"):
                 prm.uniform_(-0.1, 0.1)
     model = model.to(dev).eval()
-    eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")),
-                                   precision=args.precision)
-    names = eng.kernel_names()
 
     # every rank owns its own molecules (different seeds per rank): embarrassingly parallel shards
     pos, types, ptr, masses = synthetic.batch(args.batch, args.beads, rc, first_seed=1000 + rank * args.batch)
@@ -180,147 +406,117 @@ def main():
         beta = torch.tensor(betas, device=dev).repeat_interleave(args.batch // args.pt_betas)
         exchange = simulate.LocalReplicaExchange(betas, args.batch // args.pt_betas, args.beads, seed=5)
 
-    # Event plan.  Recording an event pair around all 15 kernels of every step costs ~0.1 ms per step (5 % of the
-    # step: measured, tools/event_overhead.py), so: (1) a few untimed profile steps with every kernel bracketed
-    # give the per-kernel table and name the dominant kernel; (2) in the timed region only the dominant kernel's
-    # launches are bracketed (its live duration is what `roofline.achieved` uses).
-    nk = len(names)
-    n_prof = 5
-    prof_events = HipEvents(2 * nk * n_prof)
-    step_no = {"i": -1, "mode": "plain", "mask": None}
-    timed_events = None
-
-    def force_fn(x):
-        i = step_no["i"]
-        if step_no["mode"] == "profile" and 0 <= i < n_prof:
-            ev = (ctypes.c_void_p * (2 * nk)).from_buffer(prof_events.ev, i * 2 * nk * ctypes.sizeof(ctypes.c_void_p))
-            return eng.energy_forces(x, types, ptr, args.beads, events=ev)
-        if step_no["mode"] == "timed" and 0 <= i < args.steps:
-            ev = (ctypes.c_void_p * (2 * nk))()
-            for j, slot in enumerate(step_no["mask"]):
-                ev[2 * slot], ev[2 * slot + 1] = timed_events.ev[(i * n_dom + j) * 2], timed_events.ev[(i * n_dom + j) * 2 + 1]
-            return eng.energy_forces(x, types, ptr, args.beads, events=ev)
-        return eng.energy_forces(x, types, ptr, args.beads)
-
-    sim = simulate.LangevinSimulation(force_fn, pos, masses, beta, args.beads, dt=0.004, friction=1.0)
-    for _ in range(args.warmup):
-        sim.timestep()
-    if exchange is not None:   # untimed first attempts: RCCL sets up its point-to-point channels on first use
-        exchange(sim)
-        exchange(sim)
-    # (1) untimed profile steps: every kernel bracketed
-    step_no["mode"] = "profile"
-    for i in range(n_prof):
-        step_no["i"] = i
-        sim.timestep()
-    torch.cuda.synchronize()
-    per = {}
-    for k, name in enumerate(names):
-        per.setdefault(name, []).extend(prof_events.elapsed_ms((i * nk + k) * 2, (i * nk + k) * 2 + 1)
-                                        for i in range(1, n_prof))
-    launches = {n: len(v) / (n_prof - 1) for n, v in per.items()}
-    prof_ms = {n: sum(v) / len(v) for n, v in per.items()}
-    dom = max(prof_ms, key=lambda n: prof_ms[n] * launches[n])
-    dom_slots = [k for k, name in enumerate(names) if name == dom]
-    n_dom = len(dom_slots)
-    timed_events = HipEvents(2 * n_dom * args.steps)
-    # clocks settle: untimed force evaluations at the CURRENT positions for --settle-seconds (nothing is integrated:
-    # the synthetic system is not stationary -- its pair count falls by 0.8 % in 500 steps, 7 % in 3600, 19 % in
-    # 20000 -- so steps here would hand the timed region a lighter workload)
-    step_no.update(mode="plain", i=-1)
-    n_settle = 0
-    t_s = time.perf_counter()
-    while time.perf_counter() - t_s < args.settle_seconds:
-        for _ in range(20):
-            force_fn(sim.x)
-        torch.cuda.synchronize()
-        n_settle += 20
-    pairs_start = eng.check_status()[2]   # workload at the start of the timed region
-    step_no.update(mode="timed", mask=dom_slots, i=-1)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # sustained-rate check (runs of >= 200 steps): device-synchronised marks after the first and before the last
-    # tenth of the timed region (two extra syncs: nothing next to hundreds of steps)
-    marks = {}
-    tenth = args.steps // 10 if args.steps >= 200 else 0
-    t_exchange, n_exchange = 0.0, 0
-    if args.reset_every:
-        x0, v0, f0, e0 = sim.x.clone(), sim.v.clone(), sim.f.clone(), sim.energy.clone()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step_no["i"] = i
-        sim.timestep()
-        if args.reset_every and (i + 1) % args.reset_every == 0:   # (three device copies of 0.4 MB, timed)
-            sim.x.copy_(x0); sim.v.copy_(v0); sim.f.copy_(f0); sim.energy.copy_(e0)
-        if exchange is not None and (i + 1) % args.exchange_interval == 0:
-            step_no["i"] = -1
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            exchange(sim)
-            torch.cuda.synchronize()
-            t_exchange += time.perf_counter() - te
-            n_exchange += 1
-        if tenth and i + 1 in (tenth, args.steps - tenth):
-            torch.cuda.synchronize()
-            marks[i + 1] = time.perf_counter() - t0
-    step_no["i"] = -1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    leg = Leg(S, engine, simulate, model, args.precision, (pos, types, ptr, masses, beta), args, barrier)
+    eng, sim = leg.eng, leg.sim
+    for _ in range(args.warmup):
+        sim.timestep()
+    if exchange is not None:   # untimed first attempts: RCCL sets up its point-to-point channels on first use
+        exchange(sim)
+        exchange(sim)
+        bytes_before = getattr(exchange, "bytes_sent", 0)
+    leg.profile()
+    n_settle = leg.settle(args.settle_seconds)
+    pairs_start = eng.check_status()[2]   # workload at the start of the timed region
+
+    # ---- the timed region (`value`), then N_REGIONS - 1 back-to-back repeats of it when it is short
+    n_dom = len(leg.dom_slots)
+    events = HipEvents(2 * n_dom * args.steps)
+    attempts = attempt_steps(args.steps, args.exchange_interval) if exchange is not None else []
+    tenth = args.steps // 10 if args.steps >= 200 else 0   # sustained-rate marks (runs of >= 200 steps)
+    elapsed, marks, t_exchange, n_exchange = leg.timed_region(args.steps, events, exchange, attempts,
+                                                              args.reset_every, tenth)
+    elapsed = max_over_ranks(elapsed)
     assert torch.isfinite(sim.x).all() and torch.isfinite(sim.f).all(), "simulation diverged"
-    st = eng.check_status()
-    n_pairs = st[2]
-    # the reference-shaped entry point users call: GradientsOut(model)(Batch) picks the same engine; a short
-    # run through it right after the timed region (its result is reported beside the line, not as `value`)
-    via_go = None
+    n_pairs = eng.check_status()[2]
+    dom_ms = leg.dominant_ms(events, args.steps) if rank == 0 else 0.0
+    regions_ms = [1e3 * elapsed / args.steps]
+    if args.steps < 200 and not args.pt:
+        for _ in range(N_REGIONS - 1):
+            e_r = max_over_ranks(leg.timed_region(args.steps, events, None, (), args.reset_every, 0)[0])
+            regions_ms.append(1e3 * e_r / args.steps)
+        assert torch.isfinite(sim.f).all(), "simulation diverged"
+        eng.check_status()
+
+    # the same loop with the engine called directly (no GradientsOut / Batch in between), reported beside the line
+    direct_ms = None
     if not args.pt:
-        go = S.GradientsOut(model).eval()
-        model._engine = eng
-
-        batch_obj = S.Batch(pos, types, ptr, max_beads_per_mol=args.beads)  # collated once, like the reference's
-        # simulation keeps one AtomicData and updates its positions (simulation/base.py:991-1020)
-
-        def force_go(x):
-            batch_obj.pos, batch_obj.out = x, {}
-            d = go(batch_obj)
-            return d.out["SchNet"]["energy"], d.out["SchNet"]["forces"]
-
-        sim.force_fn = force_go
+        sim.force_fn = leg.force_direct
         for _ in range(3):
             sim.timestep()
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        n_go = max(10, min(args.steps, 40))
-        for _ in range(n_go):
+        k_dir = min(args.steps, 200)
+        barrier()
+        td = time.perf_counter()
+        for _ in range(k_dir):
             sim.timestep()
-        torch.cuda.synchronize()
-        via_go = 1e3 * (time.perf_counter() - tg) / n_go
+        barrier()
+        direct_ms = 1e3 * max_over_ranks(time.perf_counter() - td) / k_dir
+        sim.force_fn = leg.force_via_gradients_out
+
     pt_info = None
     if exchange is not None:
         m = exchange.acceptance_matrix() if world > 1 else exchange.acceptance_matrix
         nb = m.shape[0]
         pt_info = {"betas": [round(b, 4) for b in (beta_ladder(world) if world > 1 else beta_ladder(args.pt_betas))],
                    "exchange_interval": args.exchange_interval, "attempts_timed": n_exchange,
+                   "attempted_after_steps": attempts,
+                   "attempt_schedule": ("every exchange_interval steps (reference)" if args.steps >= 2 * args.exchange_interval
+                                        else "steps//3 and 2*steps//3: the region is shorter than two intervals"),
                    "exchange_ms_per_attempt": 1e3 * t_exchange / max(1, n_exchange),
                    "accepted_per_pair": [int(m[k, k + 1]) for k in range(nb - 1)],
                    "rejected_per_pair": [int(m[k + 1, k]) for k in range(nb - 1)],
+                   "accept_reject_note": "counts include the two untimed warm-up attempts",
                    "layout": "one beta per rank, point-to-point RCCL exchange" if world > 1 else
                              f"{args.pt_betas} betas x {args.batch // args.pt_betas} replicas in one batch, in-batch HIP swap"}
+        if world > 1:
+            pt_info["rank0_bytes_sent_timed"] = exchange.bytes_sent - bytes_before
+            pt_info["rank0_payload_transfers_total"] = exchange.payload_transfers
+            pt_info["bytes_per_attempt_note"] = (f"energies {4 * args.batch} B one way, accept mask {args.batch} B back; "
+                                                 f"positions+velocities {2 * args.batch * args.beads * 12} B each way "
+                                                 "only when a pair was accepted")
+
+    # ---- W16A16 leg (BASELINE configs[2]) on the same batch, after the fp32 regions
+    w16 = None
+    if world == 1 and args.precision == "f32" and not args.pt and not args.no_w16a16_leg:
+        lg = Leg(S, engine, simulate, model, "w16a16", (pos, types, ptr, masses, beta), args, barrier)
+        for _ in range(5):
+            lg.sim.timestep()
+        lg.profile()
+        p0 = lg.eng.check_status()[2]
+        ev16 = HipEvents(2 * len(lg.dom_slots) * args.w16a16_steps)
+        e16 = lg.timed_region(args.w16a16_steps, ev16)[0]
+        assert torch.isfinite(lg.sim.f).all(), "W16A16 simulation diverged"
+        p1 = lg.eng.check_status()[2]
+        d16 = lg.dominant_ms(ev16, args.w16a16_steps)
+        flops16 = 2.0 * (p0 + p1) * 128 * (args.num_rbf + 128)
+        ach16 = flops16 / (d16 * 1e-3) / 1e12
+        raw16, _, per16, sc16 = kernel_table(lg, d16, 1e3 * e16 / args.w16a16_steps)
+        w16 = {"workload": "CGSchNet 1ENH batch=128 " + PRECISIONS["w16a16"]["cfg"] + ", same batch and model",
+               "value": args.w16a16_steps * args.batch / e16, "unit": "timestep*mol/s",
+               "ms_per_step": 1e3 * e16 / args.w16a16_steps, "steps": args.w16a16_steps, "warmup": 5, "dtype": "f16",
+               "vs_baseline": args.w16a16_steps * args.batch / e16 / PUBLISHED_BASELINE,
+               "arithmetic": PRECISIONS["w16a16"]["arith"],
+               "roofline": {"bound": "mfma", "kernel": lg.dom, "achieved": ach16, "peak": PEAK_F16_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": ach16 / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                            "peak_note": PRECISIONS["w16a16"]["note"], "algorithmic_flops_per_launch": flops16,
+                            "avg_launch_ms": d16, "launches_per_step": lg.launches[lg.dom]},
+               "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw16.items()},
+               "kernel_ms_per_step": {n: round(v, 4) for n, v in per16.items()}}
+        model._engine = eng
 
     if rank == 0:
-        # (2) the dominant kernel's device time over the timed region, events recorded on the launch stream
-        dom_ms = [timed_events.elapsed_ms((i * n_dom + j) * 2, (i * n_dom + j) * 2 + 1)
-                  for i in range(args.steps) for j in range(n_dom)]
-        avg_ms = dict(prof_ms)
-        avg_ms[dom] = sum(dom_ms) / len(dom_ms)
+        prec = PRECISIONS[args.precision]
         # directed edges of the reference's graph: the mean of the counts at the two ends of the timed region (the
         # synthetic system relaxes while it is integrated; over the default 40 steps the count moves by 0.02 %)
         n_edges = n_pairs + pairs_start
@@ -328,36 +524,30 @@ def main():
         # algorithmic FLOPs per launch: filter nets of one block, forward
         # (edge_fwd) or input-gradient backward (edge_bwd): 2*E*F*(R+F) each
         alg_flops = 2.0 * n_edges * F * (R + F)
-        achieved = alg_flops / (avg_ms[dom] * 1e-3) / 1e12
+        achieved = alg_flops / (dom_ms * 1e-3) / 1e12
         # HBM-side bytes per launch of the dominant kernel: a STORED rocprofv3 --pmc result (FETCH_SIZE / WRITE_SIZE
         # passes of tools/profile_round.sh, corrected as MI355X_MICROARCH.md prescribes), not measured in this run
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            traffic = tj.get(leg.dom, {}).get("hbm_bytes_per_launch")
             traffic_src = "stored profile: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc passes")) + ")"
+        ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps * args.batch * world / elapsed
-        prec = {
-            "f32": dict(dtype="f32", peak=PEAK_SPLIT3_TFLOPS, cfg="Langevin fp32 (BASELINE configs[1])",
-                        arith="fp32 storage and accumulation; filter-network and node GEMMs as split-operand "
-                              "f16 MFMA (x = hi + lo/2048, 3 products), error 2e-7 = fp32 MFMA grade",
-                        note="dense f16 MFMA peak (16 x 157.3) / 3 products per fp32-grade product; "
-                             "the exact-fp32 MFMA peak is 157.3"),
-            "w16a16": dict(dtype="f16", peak=PEAK_F16_MFMA_TFLOPS, cfg="W16A16 (BASELINE configs[2])",
-                           arith="filter and output networks: fp16 operands, fp32 accumulation (reference "
-                                 "W16A16 mode); node linears fp32-grade", note="dense f16 MFMA peak (16 x 157.3)"),
-        }[args.precision]
+        raw, per_step_raw, per_step, scale = kernel_table(leg, dom_ms, ms_per_step)
         line = {
             "metric": "timestep*mol/s, CGSchNet 1ENH batch=128",
             "value": value, "unit": "timestep*mol/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
             **({"rehearsal": "ranks share GPUs, gloo: not a measurement"} if rehearse else {}),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": value / PUBLISHED_BASELINE,
             "dtype": prec["dtype"], "data": "synthetic",
             "config": {"workload": "CGSchNet 1ENH batch=128 " + (prec["cfg"] if not args.pt else
                                    "parallel tempering, one beta per GPU (BASELINE configs[4])" if world > 1 else
                                    "parallel tempering, all betas in one batch (BASELINE configs[4] on one GPU)"),
+                       "entry_point": "GradientsOut(model)(batch): the reference's operator surface "
+                                      "(models/gradients.py:226-290), which dispatches to the fused HIP engine",
                        "arithmetic": prec["arith"],
                        "molecules_per_gpu": args.batch, "beads_per_molecule": args.beads,
                        "directed_edges_per_gpu": n_edges, "num_rbf": R, "interaction_blocks": args.blocks,
@@ -365,26 +555,32 @@ def main():
                        "sharding": f"replica-sharded x{world}, no collective in the force path",
                        "directed_edges_at_start_and_end_of_timed_region": [2 * pairs_start, 2 * n_pairs],
                        "reset_every": args.reset_every,
-                       "untimed": {"warmup_steps": args.warmup, "kernel_profile_steps": n_prof,
+                       "untimed": {"warmup_steps": args.warmup, "kernel_profile_steps": N_PROFILE,
                                    "clock_settle_force_evaluations": n_settle,
                                    "note": "all before the first barrier of the timed region; the settle phase evaluates "
                                            "forces at fixed positions (no integration); --settle-seconds 0 disables it"},
                        "baseline_note": "2861 = reference README (W16A16, real 1ENH, RTX PRO 6000)"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": prec["peak"],
+            "roofline": {"bound": "mfma", "kernel": leg.dom, "achieved": achieved, "peak": prec["peak"],
                          "unit": "TFLOP/s", "frac": achieved / prec["peak"],
                          "traffic": traffic if args.precision == "f32" else None,
                          "traffic_source": traffic_src if args.precision == "f32" else None,
                          "peak_note": prec["note"],
-                         "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": avg_ms[dom],
-                         "launches_per_step": launches[dom]},
-            "kernel_ms_per_launch": {n: round(v, 4) for n, v in avg_ms.items()},
-            "kernel_ms_per_step": {n: round(avg_ms[n] * launches[n], 4) for n in avg_ms},
-            "kernel_timing_note": f"{dom}: HIP events over the timed region; the other kernels: events over "
-                                  f"{n_prof - 1} untimed profile steps just before it (bracketing all 15 launches "
-                                  "of every step costs ~5 % of the step)",
+                         "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": dom_ms,
+                         "launches_per_step": leg.launches[leg.dom]},
+            "timed_regions_ms_per_step": [round(v, 5) for v in regions_ms],
+            "timed_regions_note": (f"{len(regions_ms)} back-to-back repeats of the timed region ({args.steps} steps each, "
+                                   "each between its own barrier + synchronize brackets); the first is `value`"),
+            "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw.items()},
+            "kernel_ms_per_step": {n: round(v, 4) for n, v in per_step.items()},
+            "kernel_ms_per_step_bracketed": {n: round(v, 4) for n, v in per_step_raw.items()},
+            "kernel_timing_note": f"{leg.dom}: HIP events over the timed region.  The other kernels: events over "
+                                  f"{N_PROFILE - 1} untimed steps with EVERY launch bracketed (`..._bracketed`; an event "
+                                  "record drains the stream around it, so those sums overshoot the step); in "
+                                  f"`kernel_ms_per_step` they are scaled by one factor ({scale:.3f}) so that the table "
+                                  "adds up to ms_per_step.  kernel_ms_per_launch: unscaled",
         }
-        if via_go is not None:
-            line["ms_per_step_via_GradientsOut"] = via_go
+        if direct_ms is not None:
+            line["ms_per_step_direct_engine_call"] = direct_ms
         if pt_info is not None:
             line["parallel_tempering"] = pt_info
         if marks:
@@ -392,9 +588,11 @@ def main():
             last = (elapsed - marks[args.steps - tenth]) / tenth
             line["sustained"] = {"ms_per_step_first_tenth": 1e3 * first, "ms_per_step_last_tenth": 1e3 * last,
                                  "seconds_timed": elapsed}
+        if w16 is not None:
+            line["w16a16"] = w16
         if world == 1 and not args.no_cpu_baseline and not args.pt:
             line["cpu_baseline"] = cpu_baseline(model, args)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

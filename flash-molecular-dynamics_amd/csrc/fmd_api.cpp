@@ -8,6 +8,7 @@ extern "C" const char* fmd_strerror(int code) {
     case FMD_ELAUNCH: return "HIP launch/runtime error";
     case FMD_ECAPACITY: return "fixed-capacity buffer too small";
     case FMD_EUNSUPPORTED: return "unsupported configuration";
+    case FMD_ENONFINITE: return "non-finite or overflowing force contribution";
     default: return "unknown error";
   }
 }

@@ -103,21 +103,23 @@ struct Workspace {
 };
 
 constexpr int MAX_SPLIT = 32;  // workgroups per molecule (small batches: 8 molecules x 32 = 256 workgroups)
+constexpr int MAX_CUS = 256;   // gfx950: 256 CUs in SPX mode, fewer per device in the partitioned modes
 int device_cus() {
-  int cus = 256;
+  int cus = MAX_CUS;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  return cus;
+  return cus < MAX_CUS ? cus : MAX_CUS;
 }
-int resolve_split(const fmd_schnet_desc* d, int64_t n_mol) {
+// `cus`: the device's CU count at launch; MAX_CUS when SIZING a workspace (the split falls with the CU count, so the
+// size computed for MAX_CUS covers every device: fmd_schnet_workspace_bytes is device independent)
+int resolve_split(const fmd_schnet_desc* d, int64_t n_mol, int cus) {
   if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
   // as many workgroups per molecule as fit the chip in ONE round (floor, not ceil: 100 molecules x 3 would take a second
   // round for 44 workgroups -- 0.67 of a molecule's tiles per CU against 0.5 with x 2 -- and only a launch of one round
   // gets the balanced work items)
-  const int cus = device_cus();
   int64_t s = n_mol > 0 ? cus / n_mol : 1;
   if (s < 1) s = 1;
   if (s > MAX_SPLIT) s = MAX_SPLIT;
@@ -276,7 +278,7 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
                                               int64_t n_nodes, int64_t max_pairs_per_mol) {
   if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0 || max_pairs_per_mol < 0) return FMD_EINVAL;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
-  const int split = resolve_split(desc, n_mol);  // the slabs scale with it; >= 2 for the feature-split mode
+  const int split = resolve_split(desc, n_mol, MAX_CUS);  // the slabs scale with it; >= 2 for the feature-split mode
   return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
 }
 
@@ -297,9 +299,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int L = desc->num_blocks;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
-  const int split = fs ? 2 : resolve_split(desc, n_mol);  // FS: the two feature halves
-  // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
   const int cus = device_cus();
+  const int split = fs ? 2 : resolve_split(desc, n_mol, cus);  // FS: the two feature halves
+  // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
   const bool chain = !fs && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
   const int n_slabs = chain ? 2 : split;                       // regular slabs the node kernels add
   const int64_t pair_wgs = chain ? cus : n_mol;                // grid.y of the pair kernels

@@ -551,14 +551,21 @@ __global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restri
 // two workgroups (4 waves each) per molecule, each with half of its pair list: forces from dE/dd of the pairs,
 // energy from the beads.  Each wave accumulates a private copy of dE/dpos in LDS as 64-bit FIXED POINT (2^-32): a
 // scattered ds_add_u64 costs 229 cycles per wave instruction against 768 for ds_add_f32
-// (tools/ubench/lds_atomic_int.hip), integer addition commutes -- any order of the atomics gives the same bits -- and
-// the sum is exact to 2.3e-10 absolute (|dE/dpos| < 2^31).  The four copies are added as integers, converted once; the two
-// workgroups then add their halves to the force array that pairs_kernel zeroed: two addends commute.
-__device__ __forceinline__ unsigned long long fmd_to_fixed(float x) {  // x * 2^32, floor + 32-bit fraction
-  const float fl = floorf(x);
-  const float fr = (x - fl) * 4294967296.0f;  // [0, 2^32]
-  const unsigned lo = fr >= 4294967040.0f ? 0xffffff00u : (unsigned)fr;  // (the largest float below 2^32)
-  return ((unsigned long long)(long long)(int)fl << 32) + lo;
+// (tools/ubench/lds_atomic_int.hip), integer addition commutes -- any order of the atomics gives the same bits.
+// The conversion is sign-symmetric, fixed(-x) = -fixed(x): |x| is cut into its integer part and a 32-bit fraction
+// (both exact in fp32: x * 2^32 only moves the exponent), every addend is therefore exact whenever |x| >= 2^-32 * 2^23
+// and truncated towards zero by less than 2^-32 otherwise.  A value that does not fit (|x| >= 2^31, Inf, NaN) cannot
+// be carried by an integer: it raises `bad`, and the caller of this helper then poisons the molecule's forces with NaN
+// and sets the sticky status word, so a blow-up stays as visible as it was with float atomics.  The four copies are
+// added as integers, converted once; the two workgroups then add their halves to the force array that pairs_kernel
+// zeroed: two addends commute.
+__device__ __forceinline__ unsigned long long fmd_to_fixed(float x, bool& bad) {
+  const float ax = fabsf(x);
+  bad = bad || !(ax < 2147483648.0f);          // also true for NaN
+  const float ip = truncf(ax);
+  const float fr = (ax - ip) * 4294967296.0f;  // exact, in [0, 2^32)
+  const unsigned long long q = ((unsigned long long)(unsigned)ip << 32) | (unsigned long long)(unsigned)fr;
+  return x < 0.f ? 0ull - q : q;
 }
 __device__ __forceinline__ float fmd_from_fixed(unsigned long long q) {
   return (float)((double)(long long)q * (1.0 / 4294967296.0));
@@ -583,6 +590,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   unsigned long long* gall = reinterpret_cast<unsigned long long*>(smem);
   unsigned long long* g = gall + wv * 3 * n;  // this wave's [3n] dE/dpos, fixed point
   __shared__ float esum[4];
+  __shared__ int bad_s;
+  bool bad = false;  // a contribution that the fixed-point sum cannot carry (Inf, NaN, |x| >= 2^31)
+  if (tid == 0) bad_s = 0;
   for (int i = tid; i < 12 * n; i += 256) gall[i] = 0ull;
   __syncthreads();
   const int np = npairs[m];
@@ -599,9 +609,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
     if (i != ci) {
       if (ci >= 0) {
-        atomicAdd(&g[3 * ci], fmd_to_fixed(cx));
-        atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy));
-        atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz));
+        atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
+        atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
+        atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
       }
       ci = i;
       cx = cy = cz = 0.f;
@@ -613,18 +623,18 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
       const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
       const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
       const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
-      atomicAdd(&g[3 * j], fmd_to_fixed(dx));
-      atomicAdd(&g[3 * j + 1], fmd_to_fixed(dy));
-      atomicAdd(&g[3 * j + 2], fmd_to_fixed(dz));
+      atomicAdd(&g[3 * j], fmd_to_fixed(dx, bad));
+      atomicAdd(&g[3 * j + 1], fmd_to_fixed(dy, bad));
+      atomicAdd(&g[3 * j + 2], fmd_to_fixed(dz, bad));
       cx -= dx;
       cy -= dy;
       cz -= dz;
     }
   }
   if (ci >= 0) {
-    atomicAdd(&g[3 * ci], fmd_to_fixed(cx));
-    atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy));
-    atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz));
+    atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
+    atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
+    atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
   }
   if (half == 0) {
     float e = 0.f;
@@ -632,9 +642,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     e = fmd_wave_sum(e);
     if (lane == 0) esum[wv] = e;
   }
+  if (bad) bad_s = 1;  // (benign race: every writer stores 1)
   __syncthreads();
+  const bool poisoned = bad_s != 0;
   for (int i = tid; i < 3 * n; i += 256)
-    unsafeAtomicAdd(&forces[3 * a0 + i], -fmd_from_fixed(((gall[i] + gall[3 * n + i]) + gall[6 * n + i]) + gall[9 * n + i]));
+    unsafeAtomicAdd(&forces[3 * a0 + i],
+                    poisoned ? __builtin_nanf("")
+                             : -fmd_from_fixed(((gall[i] + gall[3 * n + i]) + gall[6 * n + i]) + gall[9 * n + i]));
+  if (poisoned && tid == 0) atomicMin(&status[3], FMD_ENONFINITE);
   if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
   // the call's status words from pairs_kernel's per-molecule reports (one wave of the first workgroup; a bead-bound
   // violation outranks a capacity overflow)
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
       status[0] = err;
       status[1] = need;
       status[2] = real;
-      status[3] = 0;
+      if (err != 0) atomicMin(&status[3], err);  // sticky: only the caller clears it
     }
   }
 }

@@ -142,9 +142,11 @@ class FusedSchNetEngine:
         self.packed = packed.to(self.device)
         self._ws = None
         self._ws_key = None
-        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)
-        self._bound_key = None      # (mol_ptr identity) whose caller-supplied bead bound has been validated
+        self.status = torch.zeros(4, dtype=torch.int32, device=self.device)   # [3] is sticky: zeroed here and on read
+        self._bound_key = None      # layout whose caller-supplied bead bound has been validated ...
+        self._bound_ref = None      # ... and the tensor itself: while it is alive its address cannot be handed out again
         self._since_check = 0       # force evaluations since the status words were last read
+        self.next_events = None     # measurement hook (bench.py): events for the NEXT evaluation, whatever entry point makes it
 
     @classmethod
     def from_state_dict(cls, sd, device="cuda", prefix: str = "", **kw):
@@ -180,9 +182,17 @@ class FusedSchNetEngine:
         assert pos.dtype == torch.float32 and pos.is_contiguous() and atom_types.dtype == torch.int64
         n_nodes, n_mol = pos.shape[0], mol_ptr.numel() - 1
         # a caller-supplied bound is validated once per batch layout (one host sync); without a bound the true
-        # maximum is computed on every call (one sync each: pass the bound in a time loop)
-        key = (mol_ptr.data_ptr(), mol_ptr.numel(), mol_ptr._version, int(max_beads_per_mol))
-        fresh = key != self._bound_key
+        # maximum is computed on every call (one sync each: pass the bound in a time loop).  The validated tensor is
+        # kept alive, so an equal address means the same memory, and its version counter (absent under
+        # inference_mode: such tensors are re-validated every call) catches in-place edits; what neither sees -- a raw
+        # write through another view -- is caught by the device-side check, whose verdict lands in the sticky status
+        # word and is never lost between two reads.
+        try:
+            version = mol_ptr._version
+        except RuntimeError:
+            version = None
+        key = (mol_ptr.data_ptr(), mol_ptr.numel(), version, int(max_beads_per_mol))
+        fresh = version is None or key != self._bound_key or self._bound_ref is None
         if max_beads_per_mol <= 0 or fresh:
             true_max = int((mol_ptr[1:] - mol_ptr[:-1]).max().item()) if n_mol else 1
             if max_beads_per_mol <= 0:
@@ -190,7 +200,7 @@ class FusedSchNetEngine:
             elif true_max > max_beads_per_mol:
                 raise ValueError(f"fused engine: max_beads_per_mol={max_beads_per_mol} but the batch holds a molecule "
                                  f"of {true_max} beads")
-            self._bound_key = key
+            self._bound_key, self._bound_ref = key, mol_ptr
         if max_beads_per_mol > MAX_BEADS:
             raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {MAX_BEADS}")
         # every pair plus <= 7 pad entries per centre (8-entry segments): can never overflow
@@ -201,6 +211,8 @@ class FusedSchNetEngine:
         args = (ctypes.byref(self.desc), ptr(self.packed), ptr(pos), ptr(atom_types), ptr(mol_ptr), n_mol,
                 n_nodes, max_beads_per_mol, cap, ptr(energy), ptr(forces),
                 self._workspace(n_mol, n_nodes, cap), ptr(self.status), stream())
+        if events is None and self.next_events is not None:
+            events, self.next_events = self.next_events, None
         if events is None:
             call("fmd_schnet_energy_forces", *args)
         else:
@@ -215,14 +227,19 @@ class FusedSchNetEngine:
         return energy, forces
 
     def check_status(self):
-        """Read status[0..3] (one device sync) and raise if the last evaluation flagged a problem
-        (include/flashmd_hip.h: FMD_ECAPACITY = pair list too small, FMD_EINVAL = a molecule larger than
-        max_beads_per_mol was truncated: the results are meaningless)."""
+        """Read status[0..3] (one device sync) and raise if the last evaluation -- or, through the sticky word [3], ANY
+        evaluation since the previous read -- flagged a problem (include/flashmd_hip.h: FMD_ECAPACITY = pair list too
+        small, FMD_EINVAL = a molecule larger than max_beads_per_mol was truncated, FMD_ENONFINITE = a force
+        contribution was Inf / NaN: the results of that call are meaningless)."""
         self._since_check = 0
         st = self.status.tolist()
-        if st[0] != 0:
-            raise RuntimeError(f"fused engine: device status {st[0]} ({_ffi.strerror(st[0])}); max pairs seen in "
-                               f"one molecule {st[1]}, total pairs {st[2]}: energies and forces of that call are invalid")
+        if st[3] != 0:
+            self.status[3] = 0
+        code = st[0] or st[3]
+        if code != 0:
+            when = "the last evaluation" if st[0] else "an evaluation since the previous status read"
+            raise RuntimeError(f"fused engine: device status {code} ({_ffi.strerror(code)}) in {when}; max pairs seen "
+                               f"in one molecule {st[1]}, total pairs {st[2]}: energies and forces of that call are invalid")
         return st
 
 

@@ -323,11 +323,13 @@ class DistributedReplicaExchange:
 
     The force path never communicates.  An exchange attempt is point-to-point between the two
     partner ranks only (torch.distributed send/recv = RCCL over the direct xGMI link on GPUs, gloo
-    on CPU): energies first (n_indep floats), then positions+velocities of the batch (fixed size,
-    <= 0.83 MB at 128 x 269 beads), applied where the pair was accepted.  Both partners draw the
-    same uniform numbers from a counter-based CPU generator keyed by (seed, attempt, lower rank),
-    so they reach the same decision without a second message (the reference draws from the global
-    CPU RNG, parallel_tempering.py:394)."""
+    on CPU).  The Metropolis decision has ONE source, the lower rank of the pair: the upper rank sends
+    its energies (n_indep floats), the lower rank draws the uniform numbers (a CPU generator keyed by
+    (seed, attempt, lower rank); the reference draws from the global CPU RNG, parallel_tempering.py:394),
+    decides, and sends the accept mask back (n_indep bytes) -- two ranks can never disagree on a
+    borderline ``rand < p`` and then wait for a transfer the other never posts.  Positions+velocities of
+    the batch (fixed size, <= 0.83 MB at 128 x 269 beads) cross the link, once each way, only when at
+    least one pair was accepted, and are applied where the mask says so."""
 
     def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0, group=None):
         import torch.distributed as dist
@@ -342,6 +344,10 @@ class DistributedReplicaExchange:
         self.local_matrix = torch.zeros(self.world, self.world, dtype=torch.int64)
         self.exchange_seconds = 0.0   # wall time spent inside exchange attempts that had a partner
         self.exchanges = 0
+        self.bytes_sent = 0           # payload bytes this rank put on the link (energies / mask / x+v)
+        self.payload_transfers = 0    # attempts in which positions+velocities crossed
+        # gloo moves host memory: device tensors are staged through the CPU (tests, rehearsals); RCCL takes them as they are
+        self._stage = dist.get_backend(group) != "nccl"
 
     def partner(self, even: bool) -> Optional[int]:
         for a, b in pt_pairs(self.world, even):
@@ -350,6 +356,26 @@ class DistributedReplicaExchange:
             if self.rank == b:
                 return a
         return None
+
+    def _send(self, t, peer):
+        self.bytes_sent += t.numel() * t.element_size()
+        self.dist.send(t.cpu() if self._stage else t, peer, group=self.group)
+
+    def _recv(self, like, peer):
+        buf = torch.empty(like.shape, dtype=like.dtype, device="cpu" if self._stage else like.device)
+        self.dist.recv(buf, peer, group=self.group)
+        return buf.to(like.device)
+
+    def _swap(self, t, peer):
+        """send ``t`` to the partner and receive the partner's tensor of the same shape (one round, both ways)"""
+        dist = self.dist
+        out = t.cpu() if self._stage else t
+        inc = torch.empty_like(out)
+        self.bytes_sent += t.numel() * t.element_size()
+        ops = [dist.P2POp(dist.isend, out, peer, self.group), dist.P2POp(dist.irecv, inc, peer, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return inc.to(t.device)
 
     def __call__(self, sim: "LangevinSimulation"):
         import time
@@ -361,30 +387,25 @@ class DistributedReplicaExchange:
         if peer is None:      # an end rank sits this phase out (odd phase: ranks 0 and W-1 for even W)
             return
         t0 = time.perf_counter()
-        dist = self.dist
         lo, hi = min(self.rank, peer), max(self.rank, peer)
-        # 1. energies of the partner's replicas
         u_mine = sim.energy.detach().contiguous()
-        u_peer = torch.empty_like(u_mine)
-        ops = [dist.P2POp(dist.isend, u_mine, peer, self.group), dist.P2POp(dist.irecv, u_peer, peer, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        # 2. the same decision on both sides (a = lower rank of the pair)
-        g = torch.Generator().manual_seed((self.seed * 1000003 + attempt) * 4099 + lo)
-        rand_u = torch.rand(self.n_indep, generator=g).to(u_mine.device)
-        u_a, u_b = (u_mine, u_peer) if self.rank == lo else (u_peer, u_mine)
-        acc = pt_accept(u_a, u_b, self.betas[lo], self.betas[hi], rand_u)
-        n_acc = int(acc.sum())   # one host sync per attempt, identical on both partners
+        if self.rank == hi:
+            # 1. my energies to the deciding rank, 2. its decision back
+            self._send(u_mine, lo)
+            acc = self._recv(torch.empty(self.n_indep, dtype=torch.uint8, device=u_mine.device), lo).bool()
+        else:
+            u_peer = self._recv(u_mine, hi)
+            g = torch.Generator().manual_seed((self.seed * 1000003 + attempt) * 4099 + lo)
+            rand_u = torch.rand(self.n_indep, generator=g).to(u_mine.device)
+            acc = pt_accept(u_mine, u_peer, self.betas[lo], self.betas[hi], rand_u)
+            self._send(acc.to(torch.uint8), hi)
+        n_acc = int(acc.sum())   # one host sync per attempt; the same mask on both partners by construction
         if self.rank == lo:
             pt_count(self.local_matrix, lo, hi, n_acc, self.n_indep)
         if n_acc:
             # 3. positions and velocities of the whole batch cross the link once, each way
-            payload = torch.stack([sim.x, sim.v]).contiguous()
-            incoming = torch.empty_like(payload)
-            ops = [dist.P2POp(dist.isend, payload, peer, self.group),
-                   dist.P2POp(dist.irecv, incoming, peer, self.group)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            incoming = self._swap(torch.stack([sim.x, sim.v]).contiguous(), peer)
+            self.payload_transfers += 1
             # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
             #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
             mask = acc.repeat_interleave(self.n_atoms)[:, None]

@@ -29,6 +29,7 @@ extern "C" {
 #define FMD_ELAUNCH (-2)    /* HIP reported a launch error */
 #define FMD_ECAPACITY (-3)  /* a fixed-capacity buffer was too small (reported by the *_status call) */
 #define FMD_EUNSUPPORTED (-4)
+#define FMD_ENONFINITE (-5) /* a force contribution was Inf / NaN / >= 2^31 (reported in the sticky status word) */
 
 const char* fmd_strerror(int code);
 /* ABI version of this library (bumped on any signature change). */
@@ -217,9 +218,14 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
                                    int64_t max_pairs_per_mol);
 /* status[0..3] (int32, device): [0] = 0 ok / FMD_ECAPACITY (pair list too small) / FMD_EINVAL (a molecule has more
  * beads than max_beads_per_mol: it was truncated to stay inside the LDS sized for that bound -- results are
- * meaningless), [1] = max pairs seen in one molecule,
- * [2] = total pairs, [3] reserved (0). All four words are written by the call's last kernel (nothing has to be
- * zeroed beforehand); read them back at the caller's convenience.  forces / energy are fully overwritten. */
+ * meaningless), [1] = max pairs seen in one molecule, [2] = total pairs: these three are written by every call's last
+ * kernel (nothing to zero).  [3] is STICKY: the most negative error code of any call since the caller last zeroed it
+ * (the codes of [0], or FMD_ENONFINITE when a force contribution was Inf / NaN / >= 2^31 -- the forces of that
+ * molecule are then NaN, never a finite wrong number).  The caller zeroes [3] once and after every read; it may then
+ * read the words every few hundred calls without missing a failed call in between.  forces / energy are fully
+ * overwritten.
+ * The workspace size does not depend on the current device (it is computed for the largest split any gfx950
+ * partition mode can choose), so a workspace sized under one device is valid under another. */
 /* max_beads_per_mol: upper bound on beads of one molecule.  The per-molecule aggregate lives in LDS: up to 283
  * beads in one workgroup; 284..535 beads in feature-split mode (two workgroups per molecule, 64 features each).
  * Larger molecules return FMD_EUNSUPPORTED and take the operator path.

@@ -207,3 +207,50 @@ def test_state_dict_loaders_row_n4(tmp_path, golden_dir):
         data = S.GradientsOut(models[1]).eval()(S.Batch(pos.clone(), types, ptr))
         f = data.out["SchNet"]["forces"].double().numpy()
         assert np.linalg.norm(f - z["forces_ref64"]) / np.linalg.norm(z["forces_ref64"]) < 1e-5
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (no RANK in the environment: how the driver starts the single-GPU line) must start N
+    ranks itself -- as a child `python -m torch.distributed.run ... bench.py <same args>`, rendezvous on 127.0.0.1 --
+    and relay rank 0's line; under torch.distributed.run (RANK set) it must not launch again."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    a = bench.parse(["--gpus", "8", "--pt"])
+    assert bench.needs_self_launch(a, {}) and not bench.needs_self_launch(a, {"RANK": "3"})
+    assert not bench.needs_self_launch(bench.parse([]), {})
+    argv = bench.launcher_argv(8, 29512, ["--gpus", "8", "--pt", "--steps", "40"])
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29512"
+    assert argv[-5:] == ["--gpus", "8", "--pt", "--steps", "40"] and argv[-6].endswith("bench.py")
+    # the real thing, two ranks on the CPU: the launch path only (FMD_BENCH_LAUNCH_CHECK stops before any GPU use)
+    env = dict(os.environ, FMD_BENCH_LAUNCH_CHECK="1")
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "rank_sum": 1, "gpus_arg": 2}
+
+
+def test_bench_exchange_attempts_fall_inside_a_short_timed_region():
+    """--pt must time at least one even- and one odd-phase attempt whatever --steps is (the driver runs 40 steps against
+    an exchange interval of 100); long regions keep the reference's schedule (parallel_tempering.py:349-366)."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    assert bench.attempt_steps(40, 100) == [13, 26]
+    assert bench.attempt_steps(199, 100) == [66, 132]
+    assert bench.attempt_steps(200, 100) == [100, 200]
+    assert bench.attempt_steps(1000, 100) == list(range(100, 1001, 100))
+    for k in range(2, 60):
+        a = bench.attempt_steps(k, 100)
+        assert len(a) == 2 and 1 <= a[0] < a[1] <= k
+    assert bench.attempt_steps(1, 100) == [1] and bench.attempt_steps(0, 100) == []

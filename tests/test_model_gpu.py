@@ -407,14 +407,84 @@ def test_wrong_bead_bound_raises_and_device_flag_is_read(params):
     with pytest.raises(ValueError):
         S.GradientsOut(model).eval()(S.Batch(P, T, Q, max_beads_per_mol=40))
     # the device-side flag, reached by skipping the host validation
-    eng._bound_key = (Q.data_ptr(), Q.numel(), Q._version, 40)
+    eng._bound_key, eng._bound_ref = (Q.data_ptr(), Q.numel(), Q._version, 40), Q
     eng.energy_forces(P, T, Q, 40)
     with pytest.raises(RuntimeError):
         eng.check_status()
     e, f = eng.energy_forces(P, T, Q, 60)
     assert eng.check_status()[0] == 0
+    # the flag is STICKY: a bad evaluation followed by good ones is still reported at the next read (the host reads the
+    # status words only every engine.STATUS_CHECK_EVERY evaluations) -- and only once
+    eng._bound_key, eng._bound_ref = (Q.data_ptr(), Q.numel(), Q._version, 40), Q
+    eng.energy_forces(P, T, Q, 40)
+    eng._bound_key = (Q.data_ptr(), Q.numel(), Q._version, 60)   # (a layout the host has "seen": no read on the way)
+    for _ in range(3):
+        eng.energy_forces(P, T, Q, 60)
+    assert int(eng.status[0]) == 0 and int(eng.status[3]) != 0
+    with pytest.raises(RuntimeError, match="since the previous status read"):
+        eng.check_status()
+    assert eng.check_status()[3] == 0
+    # a freshly built mol_ptr with other contents at a recycled address is validated again (the validated tensor is
+    # kept alive, so the address cannot be recycled while it is the cache key)
+    held = eng._bound_ref
+    Q2 = torch.tensor([0, 30, 120], device=DEV)
+    assert Q2.data_ptr() != held.data_ptr()
+    with pytest.raises(ValueError):
+        eng.energy_forces(P, T, Q2, 60)         # a 90-bead molecule under a bound of 60
     e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos.double(), types, ptr)
     assert _relerr(e, f, e_o.numpy(), f_o.numpy())[1] < 1e-4
+
+
+def test_non_finite_weights_stay_visible_in_the_forces(params):
+    """The final reduction adds dE/dpos as 64-bit fixed point (integer atomics).  An integer cannot carry NaN / Inf: a
+    contribution that does not fit must poison the molecule's forces and set the sticky status word instead of turning
+    into a finite (zero) force next to a NaN energy.  Molecules without such a contribution are untouched."""
+    import copy
+
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(3, 60, 5.0)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    good = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e0, f0 = good.energy_forces(P, T, Q, 60)
+    for bad_value in (float("nan"), float("inf")):
+        p_bad = copy.deepcopy(params)
+        p_bad["out"][0]["w"][3, 5] = bad_value
+        eng = engine.FusedSchNetEngine(S.model_from_params(p_bad).to(DEV))
+        e, f = eng.energy_forces(P, T, Q, 60)
+        assert not torch.isfinite(e).any()
+        assert not torch.isfinite(f).any(), "non-finite dE/dd became finite forces"
+        assert int(eng.status[3]) == -5   # FMD_ENONFINITE
+        with pytest.raises(RuntimeError, match="non-finite"):
+            eng.check_status()
+    del e0, f0
+
+
+def test_fixed_point_force_sum_is_sign_symmetric(params):
+    """Mirror image of a molecule: every dE/dpos contribution changes sign, so the fixed-point sums must be exact
+    negatives of each other (the conversion is sign-symmetric), also for contributions far below 2^-24."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(2, 60, 5.0)
+    pos[60:] = -pos[:60]                 # point reflection: same distances, opposite direction vectors
+    types[60:] = types[:60]
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 60)
+    assert torch.equal(e[0], e[1])
+    assert torch.equal(f[:60], -f[60:])
+    # tiny weights -> tiny forces (|F| ~ 1e-9): still the oracle's, to 2^-32 absolute per contribution
+    import copy
+    p_small = copy.deepcopy(params)
+    p_small["out"][-1]["w"] = p_small["out"][-1]["w"] * 1e-9
+    eng = engine.FusedSchNetEngine(S.model_from_params(p_small).to(DEV))
+    e, f = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 60)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(p_small, torch.float64), pos.double(), types, ptr)
+    err = (f.double().cpu() - f_o).abs().max().item()
+    print(f"tiny forces: max |F| {f_o.abs().max().item():.2e}, max abs error {err:.2e}")
+    assert torch.equal(f[:60], -f[60:])
+    assert err < 60 * 2.0 ** -32        # <= one truncation of 2^-32 per contribution, ~60 contributions per bead
 
 
 def test_neighbour_list_semantics_of_the_reference(params):

@@ -6,7 +6,7 @@ cp $LIB /tmp/lib_orig.so
 for pass in 1 2; do
   for v in "$@"; do
     cp $v $LIB
-    timeout -k 10 200 python bench.py --no-cpu-baseline $BENCH_ARGS > /tmp/ab.json 2>/dev/null
+    timeout -k 10 200 python bench.py --no-cpu-baseline --no-w16a16-leg $BENCH_ARGS > /tmp/ab.json 2>/dev/null
     python - "$v" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))
