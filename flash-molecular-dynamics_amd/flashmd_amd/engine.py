@@ -149,13 +149,15 @@ class FusedSchNetEngine:
         self.next_events = None     # measurement hook (bench.py): events for the NEXT evaluation, whatever entry point makes it
 
     @classmethod
-    def from_state_dict(cls, sd, device="cuda", prefix: str = "", **kw):
+    def from_state_dict(cls, sd, device="cuda", prefix: Optional[str] = None, cutoff: Optional[float] = None, **kw):
         """Engine from a ``state_dict`` keyed by the reference's parameter names (a dict, an ``.npz`` or a
-        weights-only ``torch.load`` file; see ``schnet.model_from_state_dict``).  Raises ValueError when the model is
-        outside the engine's envelope (hidden = filters = 128, 2 <= num_rbf <= 64, 2-3 output linears)."""
+        weights-only ``torch.load`` file; ``prefix=None`` finds the SchNet inside a ``GradientsOut`` / ``SumOut``
+        container; ``cutoff``: see ``schnet.model_from_state_dict`` -- hyper-parameters the weights do not encode).
+        Raises ValueError when the model is outside the engine's envelope (hidden = filters = 128,
+        2 <= num_rbf <= 64, 2-3 output linears)."""
         from .schnet import model_from_state_dict
 
-        return cls(model_from_state_dict(sd, prefix).to(device).eval(), **kw)
+        return cls(model_from_state_dict(sd, prefix, cutoff).to(device).eval(), **kw)
 
     def _workspace(self, n_mol, n_nodes, cap):
         key = (n_mol, n_nodes, cap)

@@ -88,6 +88,39 @@ def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
                      + [tables["k2s"][i][idx].unsqueeze(0) for i in range(n)])
 
 
+def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Tensor]]]:
+    """The prior models of a reference-format container, read from its ``state_dict``: name -> (kind, per-type tables).
+    The reference's prior classes keep their parameters as BUFFERS indexed by bead types: ``Harmonic.x_0`` / ``.k``
+    (prior/harmonic.py:60-77; order 2 = bonds, order 3 = angles), ``Repulsion.sigma`` (prior/repulsion.py:52-60),
+    ``FourierSeries.k1s`` / ``.k2s`` / ``.v_0`` (prior/fourier_series.py:60-80; order 4 = dihedrals), each under
+    ``<prefix>.<name>.model.`` in ``SumOut.models`` (models/gradients.py:64-69).  The kind is told by the buffer set and
+    its rank, the name is the ModuleDict key -- the key of ``data.neighbor_list`` the term's index mapping lives
+    under.  The topology itself is not in the file: ``StaticPriors.from_state_dict`` takes it from the caller."""
+    groups: Dict[str, Dict[str, torch.Tensor]] = {}
+    for key, v in sd.items():
+        head, _, leaf = key.rpartition(".")
+        if leaf in ("x_0", "k", "sigma", "k1s", "k2s", "v_0"):
+            groups.setdefault(head, {})[leaf] = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+    out = {}
+    for head, bufs in groups.items():
+        parts = head.split(".")
+        name = parts[-2] if parts[-1] == "model" and len(parts) >= 2 else parts[-1]
+        names = set(bufs)
+        if names == {"x_0", "k"} and bufs["k"].dim() == 2:
+            kind = "bonds"
+        elif names == {"x_0", "k"} and bufs["k"].dim() == 3:
+            kind = "angles"
+        elif names == {"sigma"} and bufs["sigma"].dim() == 2:
+            kind = "repulsion"
+        elif names == {"k1s", "k2s", "v_0"} and bufs["v_0"].dim() == 4:
+            kind = "dihedrals"
+        else:
+            raise ValueError(f"state_dict entry {head!r} looks like a prior ({sorted(names)}, rank "
+                             f"{[int(b.dim()) for b in bufs.values()]}) of a kind this build does not evaluate")
+        out[name] = (kind, bufs)
+    return out
+
+
 class StaticPriors:
     """All prior terms of a collated batch, condensed: for each kind ``mapping`` [order, M] (int64, global bead
     indices), ``params`` [P, M] (fp32) and the by-bead CSR of the fixed topology (``bead_ptr`` [N+1] int64,
@@ -124,6 +157,28 @@ class StaticPriors:
                 pair = (word.to(torch.uint32) if hasattr(torch, "uint32") else word, params[:, t].contiguous())
             terms[kind] = (mapping.contiguous(), params.contiguous(), bead_ptr, ents.to(torch.int32).contiguous(), pair)
         return cls(terms, int((mol_ptr[1:] - mol_ptr[:-1]).max()))
+
+    @classmethod
+    def from_state_dict(cls, sd, topology: Dict[str, torch.Tensor], types, mol_ptr):
+        """Row N4: the condensed priors of a reference-format ``SumOut`` container (what
+        ``condense_all_priors_for_simulation`` builds from the model, simulation/specialize_prior.py:76-207) from its
+        ``state_dict`` -- a dict, an ``.npz`` or a weights-only ``torch.load`` file -- plus the index mappings
+        ``topology[name]`` [order, M] (global bead indices of the collated batch: ``data.neighbor_list[name]
+        ["index_mapping"]``), bead types [N] and mol_ptr [B+1] on the CPU.  Every prior in the file needs its mapping;
+        two priors of one kind (e.g. two bond models) are not condensed into one here and raise."""
+        if isinstance(sd, str):
+            from .schnet import _state_dict_from_file
+
+            sd = _state_dict_from_file(sd)
+        found = prior_tables_from_state_dict(sd)
+        spec = {}
+        for name, (kind, tables) in found.items():
+            if name not in topology:
+                raise KeyError(f"prior {name!r} ({kind}) is in the state_dict but topology has no index mapping for it")
+            if kind in spec:
+                raise ValueError(f"two priors of kind {kind!r} in one state_dict")
+            spec[kind] = (tables, topology[name].to(torch.int64))
+        return cls.from_tables(spec, types, mol_ptr)
 
     def to(self, device):
         mv = lambda t: None if t is None else (tuple(u.to(device) for u in t) if isinstance(t, tuple) else t.to(device))  # noqa: E731

@@ -392,33 +392,63 @@ def _state_dict_from_file(path: str) -> dict:
     return sd
 
 
-def model_from_state_dict(sd, prefix: str = "") -> StandardSchNet:
-    """Row N4 (the buildable part): a ``StandardSchNet`` from a state_dict keyed by the reference's parameter names
-    (reference models/schnet.py:778-841; the same names this mirror uses: ``embedding_layer.weight``,
-    ``rbf_layer.offset`` / ``.coeff``, ``interaction_blocks.<l>.conv.{lin1,lin2,filter_network.layers.<k>}``,
-    ``interaction_blocks.<l>.lin``, ``output_network.layers.<k>``).  Hyper-parameters are read off the shapes; the
-    cutoff is the last Gaussian centre (``GaussianBasis.offset = linspace(cutoff_lower, cutoff_upper)``,
-    radial_basis/gaussian.py:71-75).  ``sd``: a dict or a path (``.npz`` or a weights-only ``torch.load`` file);
-    ``prefix``: e.g. ``"model."`` when the SchNet sits inside a wrapper such as ``GradientsOut``."""
+def find_schnet_prefix(sd) -> str:
+    """Prefix under which a StandardSchNet sits in a state_dict: "" for the bare model, "model." inside a
+    ``GradientsOut``, "models.SchNet.model." inside the reference's ``SumOut`` container (models/gradients.py:19-152:
+    ``SumOut.models[name] = GradientsOut(model)``) -- whatever precedes ``embedding_layer.weight``."""
+    hits = [k[: -len("embedding_layer.weight")] for k in sd if k.endswith("embedding_layer.weight")]
+    hits = [p for p in hits if p + "rbf_layer.offset" in sd and p + "interaction_blocks.0.conv.lin1.weight" in sd]
+    if len(hits) != 1:
+        raise KeyError(f"state_dict holds {len(hits)} StandardSchNet-shaped sub-models (prefixes {hits}); pass prefix=")
+    return hits[0]
+
+
+def model_from_state_dict(sd, prefix: Optional[str] = None, cutoff: Optional[float] = None,
+                          max_num_neighbors: int = 1000) -> StandardSchNet:
+    """Row N4: a ``StandardSchNet`` from a state_dict keyed by the reference's parameter names (reference
+    models/schnet.py:778-841; the same names this mirror uses: ``embedding_layer.weight``, ``rbf_layer.offset`` /
+    ``.coeff``, ``interaction_blocks.<l>.conv.{lin1,lin2,filter_network.layers.<k>}``, ``interaction_blocks.<l>.lin``,
+    ``output_network.layers.<k>``).  ``sd``: a dict or a path (``.npz`` or a weights-only ``torch.load`` file);
+    ``prefix``: where the SchNet sits (None: found by ``find_schnet_prefix``, so a ``GradientsOut`` / ``SumOut``
+    container's state_dict loads as it is).
+
+    A state_dict does not encode every hyper-parameter.  Read off the shapes: widths, number of blocks, basis size,
+    embedding size.  NOT in the file and therefore fixed or to be supplied: the activation (tanh, the reference's
+    default and the only one the HIP path implements), the cutoff function (``CosineCutoff`` with lower bound 0), and
+    the cutoff radius: ``cutoff=None`` takes the last Gaussian centre, which is right for the reference's untrained
+    basis (``offset = linspace(0, cutoff, R)``, ``coeff = -0.5 / (offset[1] - offset[0])**2``,
+    radial_basis/gaussian.py:56-75) and is VERIFIED against exactly that form -- a trained basis
+    (``trainable=True`` registers both as Parameters) does not pass and needs ``cutoff=`` spelled out."""
     if isinstance(sd, str):
         sd = _state_dict_from_file(sd)
+    if prefix is None:
+        prefix = find_schnet_prefix(sd)
     sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     need = ["embedding_layer.weight", "rbf_layer.offset", "interaction_blocks.0.conv.lin1.weight"]
     missing = [k for k in need if k not in sd]
     if missing:
         raise KeyError(f"state_dict lacks {missing}: not a StandardSchNet under the reference's names")
     emb = sd["embedding_layer.weight"]
-    offset = sd["rbf_layer.offset"].flatten()
+    offset = sd["rbf_layer.offset"].flatten().to(torch.float32)
     n_blocks = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("interaction_blocks."))
     filt = sd["interaction_blocks.0.conv.filter_network.layers.0.weight"]
     out_idx = sorted({int(k.split(".")[2]) for k in sd if k.startswith("output_network.layers.") and k.endswith(".weight")})
     widths = [int(sd[f"output_network.layers.{i}.weight"].shape[0]) for i in out_idx[:-1]]
-    if float(offset[0]) != 0.0:
-        raise ValueError("rbf_layer.offset does not start at 0: cutoff_lower != 0 is outside this build")
-    rc = float(offset[-1])
+    if cutoff is None:
+        rc = float(offset[-1])
+        lin = torch.linspace(0.0, rc, offset.numel())
+        coeff = sd.get("rbf_layer.coeff")
+        want = -0.5 / float(lin[1] - lin[0]) ** 2
+        if float(offset[0]) != 0.0 or not torch.allclose(offset, lin, rtol=1e-6, atol=1e-6 * rc) \
+                or coeff is None or abs(float(coeff) - want) > 1e-5 * abs(want):
+            raise ValueError("rbf_layer.offset / .coeff are not the untrained basis linspace(0, cutoff, R), "
+                             "-0.5 / spacing^2 (cutoff_lower != 0 or a trained basis): the cutoff radius cannot be "
+                             "read off the weights, pass cutoff=")
+    else:
+        rc = float(cutoff)
     m = StandardSchNet(GaussianBasis(CosineCutoff(0.0, rc), int(offset.numel())), CosineCutoff(0.0, rc), widths,
                        hidden_channels=int(emb.shape[1]), embedding_size=int(emb.shape[0]),
-                       num_filters=int(filt.shape[0]), num_interactions=n_blocks)
+                       num_filters=int(filt.shape[0]), num_interactions=n_blocks, max_num_neighbors=max_num_neighbors)
     m.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()}, strict=True)
     return m
 

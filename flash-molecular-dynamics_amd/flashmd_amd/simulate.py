@@ -85,8 +85,12 @@ class LangevinSimulation:
         self.energy, self.f = self.force_fn(self.x)
         self.n_sims = beta_mol.numel()
 
+    def draw_noise(self):
+        """fills self.noise with N(0,1) (reference langevin.py:146: ``_noise_buffer.normal_(generator=self.rng)``)"""
+        self.noise.normal_(generator=self.rng)
+
     def timestep(self):
-        self.noise.normal_(generator=self.rng)  # reference langevin.py:146
+        self.draw_noise()
         if self.use_hip:
             langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt,
                          self.friction)
@@ -113,6 +117,8 @@ class LangevinSimulation:
         half = n_timesteps // 2
         t0 = None
         sync = torch.cuda.synchronize if self.x.is_cuda else (lambda: None)
+        if writer is not None and writer.index == 0 and writer.count == 0:
+            writer.write_initial_checkpoint(self)
         for t in range(n_timesteps):
             if t == half:
                 sync()
@@ -264,6 +270,17 @@ class TrajectoryWriter:
         self.index += 1
         self.count = 0
 
+    def write_initial_checkpoint(self, sim):
+        """``{filename}_checkpoint_init.pt``: the state before the first step of a fresh run (reference
+        simulation/base.py:545-559), same keys as the per-chunk checkpoints, ``current_timestep`` 0."""
+        if not self.create_checkpoints:
+            return
+        path = f"{self.filename}_checkpoint_init.pt"
+        torch.save({"pos": sim.x.detach().cpu().clone(), "velocities": sim.v.detach().cpu().clone(),
+                    "current_timestep": 0, "export_interval": self.export_interval,
+                    "save_interval": self.save_interval, "log_interval": self.log_interval}, path)
+        self.files.append(path)
+
     def _join(self):
         if self._worker is not None:
             self._worker.join()
@@ -274,6 +291,40 @@ class TrajectoryWriter:
     def close(self):
         """Wait for the pending chunk (frames of an incomplete chunk are dropped, as in the reference)."""
         self._join()
+
+
+def force_fn_from_state_dict(sd, atom_types, mol_ptr, topology=None, device="cuda", max_beads_per_mol: int = 0,
+                             cutoff: Optional[float] = None, **engine_kw):
+    """Row N4: the force provider of a reference-format model file.  ``sd``: the ``state_dict`` of the reference's
+    ``SumOut{SchNet: GradientsOut(StandardSchNet), <prior name>: GradientsOut(<prior>) ...}`` container
+    (models/gradients.py:19-152; a dict, an ``.npz``, or a weights-only ``torch.load`` file -- never the pickled
+    module) or of a bare / ``GradientsOut``-wrapped SchNet.  Returns ``force_fn(pos) -> (energy[B], forces[N,3])`` =
+    fused SchNet engine + condensed priors (``prior.sum_out``), with ``check_status``; ``force_fn.engine`` and
+    ``force_fn.priors`` expose the parts.  ``topology``: prior name -> index mapping [order, M] of the collated batch
+    (needed when the file holds priors: a state_dict does not carry the topology); ``atom_types`` [N], ``mol_ptr`` [B+1]
+    (CPU or device).  Hyper-parameters the weights do not encode: see ``schnet.model_from_state_dict``."""
+    from . import engine as _engine
+    from . import prior as _prior
+    from .schnet import _state_dict_from_file
+
+    if isinstance(sd, str):
+        sd = _state_dict_from_file(sd)
+    eng = _engine.FusedSchNetEngine.from_state_dict(sd, device=device, cutoff=cutoff, **engine_kw)
+    types_d, ptr_d = atom_types.to(device), mol_ptr.to(device)
+    mb = int(max_beads_per_mol) or int((mol_ptr[1:] - mol_ptr[:-1]).max())
+
+    def schnet_fn(pos):
+        return eng.energy_forces(pos, types_d, ptr_d, mb)
+
+    schnet_fn.check_status = eng.check_status
+    parts = [schnet_fn]
+    priors = None
+    if _prior.prior_tables_from_state_dict(sd):
+        priors = _prior.StaticPriors.from_state_dict(sd, topology or {}, atom_types.cpu(), mol_ptr.cpu()).to(device)
+        parts.append((priors, ptr_d))
+    fn = _prior.sum_out(parts)
+    fn.engine, fn.priors = eng, priors
+    return fn
 
 
 class NVESimulation(LangevinSimulation):
