@@ -303,28 +303,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       __syncthreads();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < t_end; t += S) {
-        // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
-        f32x16 acc1 = zero16();
-        {
-          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
-          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
-          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
-          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
-          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
-          static_for<0, 8>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            f16x8 ahn = ah1, aln = al1;
-            if constexpr (s + 2 < 8) {
-              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
-              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
-            }
-            FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
-            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
-        FMD_MARK(0)
+        // Order inside the A-B window: the update of tile t-S first, L1 of tile t second.  After barrier A the producer
+        // that shares this SIMD starts with the 12 MFMAs of the next tile's layer 0; with L1 in front the two bursts
+        // met on the matrix pipe.  The update (VALU / LDS / gathers) runs under that burst, and L1 under the producer's
+        // tanh arithmetic.
         // aggregate update of tile t-S (X holds its gathers) interleaved with the refill of X for tile t, segment by
         // segment: the next segment's aggregate rows are requested, then the finished segment's registers take the new
         // offsets and its gathers are issued while that LDS read is in flight (a gather costs the CU's address unit
@@ -367,6 +349,28 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             if constexpr (q + 1 < 4) seg_reads(std::integral_constant<int, q + 1>{});
             __builtin_amdgcn_sched_barrier(0);
             seg_refill(qc);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        FMD_MARK(0)
+        // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
+        f32x16 acc1 = zero16();
+        {
+          // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
+          // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
+          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
+          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          static_for<0, 8>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f16x8 ahn = ah1, aln = al1;
+            if constexpr (s + 2 < 8) {
+              ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
+              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+            }
+            FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
+            ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
             __builtin_amdgcn_sched_barrier(0);
           });
         }

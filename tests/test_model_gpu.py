@@ -452,6 +452,9 @@ def test_non_finite_weights_stay_visible_in_the_forces(params):
         p_bad = copy.deepcopy(params)
         p_bad["out"][0]["w"][3, 5] = bad_value
         eng = engine.FusedSchNetEngine(S.model_from_params(p_bad).to(DEV))
+        with pytest.raises(RuntimeError, match="non-finite"):   # the first evaluation of a layout reads the status words
+            eng.energy_forces(P, T, Q, 60)
+        assert eng._bound_ref is Q                              # (validated: the next call does not read them)
         e, f = eng.energy_forces(P, T, Q, 60)
         assert not torch.isfinite(e).any()
         assert not torch.isfinite(f).any(), "non-finite dE/dd became finite forces"
