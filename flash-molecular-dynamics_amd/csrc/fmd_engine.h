@@ -122,6 +122,7 @@ struct NodeOutArgs {
   const float* po[3];   // packed output linears
   const float* bo[3];   // biases (zero-filled when absent)
   const float* pot[3];  // packed transposes
+  const float* w_last;  // [128] the last layer's weight vector (Linear(w, 1), no bias), zero beyond its width
   float* e_node;        // [N]
   float* gx;            // [N,128] dE/dx_L
   int64_t n_nodes;

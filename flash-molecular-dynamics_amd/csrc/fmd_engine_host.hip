@@ -266,6 +266,10 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     const int ow = desc->out_width[k];
     pack_node(base, wt->out_w[k], ow, in_w, false);
     if (wt->out_b[k]) memcpy(base + SLICE, wt->out_b[k], ow * sizeof(float));
+    // the last layer (Linear(in_w, 1), no bias): its weight vector, plain, in the bias slot -- node_out evaluates that
+    // layer and the first backward stage on registers
+    if (k == desc->num_out - 1)
+      for (int i = 0; i < in_w; ++i) base[SLICE + i] = wt->out_w[k][i];
     if (desc->precision == FMD_PREC_W16A16)
       for (int f = 0; f < F; ++f) base[SLICE + f] = (float)(_Float16)base[SLICE + f];
     pack_node(base + SLICE + F, wt->out_w[k], in_w, ow, true);  // (W^T)[o=in][k=out] = W[out][in]
@@ -393,6 +397,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
       const float* base = pk + PL.outs + kk * PL.out_stride;
       oa.po[k] = base; oa.bo[k] = base + SLICE; oa.pot[k] = base + SLICE + F;
     }
+    oa.w_last = pk + PL.outs + (desc->num_out - 1) * PL.out_stride + SLICE;
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
     ev_begin();
     rc = launch_node_out(oa, desc->num_out, half, res_grid, s);

@@ -254,24 +254,30 @@ __device__ __forceinline__ f32x16 gemm_cols_half(const _Float16* tile, const BFr
   return acc;
 }
 
-// node_out in the transposed form (see node_fwd_res_kernel); its 2 + 2 NUM_OUT operands do not fit the register
-// file, so they stay double-buffered: the next GEMM's operand is requested (L2) before the current GEMM runs
+// node_out in the transposed form (see node_fwd_res_kernel); its operands do not fit the register file, so they stay
+// double-buffered: the next GEMM's operand is requested (L2) before the current GEMM runs.
+// The output network ends in Linear(w, 1) without bias and the backward pass starts from dE/de = 1, so its last layer
+// is a dot product of each row with ONE weight vector and the first backward stage is that vector times (1 - h^2):
+// both run on the registers that hold the last hidden layer (no GEMM, no operand, no LDS tile; they were two padded
+// 128 x 128 stages of eight, each with its 64 KB operand streamed from L2).
 template <int NUM_OUT, bool HOUT>
 __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * NPLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * NPLANE];
+  __shared__ float e_part[2][4][32];  // per-wave partial energies of a tile's rows (double-buffered over tiles)
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, nl = lane & 31;
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
-  constexpr int NOPS = 2 + 2 * NUM_OUT;
+  constexpr int NH = NUM_OUT - 1;      // hidden layers of the output network (tanh, with bias)
+  constexpr int NOPS = 2 + 2 * NH;     // lin2, lin, po[0..NH-1], pot[NH-1..0]
   const float* ops[NOPS];
   ops[0] = a.l2;
   ops[1] = a.l3;
 #pragma unroll
-  for (int k = 0; k < NUM_OUT; ++k) {
+  for (int k = 0; k < NH; ++k) {
     ops[2 + k] = a.po[k];
-    ops[2 + NUM_OUT + k] = a.pot[NUM_OUT - 1 - k];
+    ops[2 + NH + k] = a.pot[NH - 1 - k];
   }
   // Operand idx lives in buffer idx & 1.  The request for operand idx + 2 goes out right BEHIND GEMM idx, into the
   // buffer that GEMM has just read: it then has the whole next stage plus this stage's epilogue to arrive (requested
@@ -297,14 +303,16 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
   load_bfrag(fb0, ops[0], w, lane);
   load_bfrag(fb1, ops[1], w, lane);
   const f32x16 b2 = load_cols(a.b2, 0, 1, w, h), b3 = load_cols(a.b3, 0, 1, w, h);
-  const bool col0 = w == 0 && h == 0;  // this lane's register 0 is column 0
   // the hidden layers' biases stay in registers: loaded inside the tile loop, each stage's wait for its 64 bytes of
   // bias was a wait for every operand request in flight as well (the counter is in order)
-  f32x16 bo_r[NUM_OUT - 1];
+  f32x16 bo_r[NH];
 #pragma unroll
-  for (int k = 0; k < NUM_OUT - 1; ++k) bo_r[k] = load_cols(a.bo[k], 0, 1, w, h);
+  for (int k = 0; k < NH; ++k) bo_r[k] = load_cols(a.bo[k], 0, 1, w, h);
+  // the last layer's weight vector, this lane's 16 columns (zero beyond the layer's width; W16A16: its fp16 values)
+  const f32x16 wl = load_cols(a.w_last, 0, 1, w, h);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // everything requested so far has landed (see node_fwd_res_kernel)
-  for (; tile < n_tiles; tile += gridDim.x) {
+  int par = 0;
+  for (; tile < n_tiles; tile += gridDim.x, par ^= 1) {
     const int64_t row = tile * 32 + nl, next = tile + gridDim.x;
     const bool ok = row < a.n_nodes;
     rows_commit(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
@@ -325,11 +333,11 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
     for (int r = 0; r < 16; ++r) acc[r] = ok ? x_old[r] + (acc[r] + b3[r]) : 0.f;
     put(bufX, acc);
     lds_barrier();
-    // ---- output network forward (tanh hidden layers, last layer linear without bias)
-    f32x16 hk[2];
+    // ---- output network forward: tanh hidden layers ...
+    f32x16 hk[NH];
     _Float16* cur = bufX;
     _Float16* nxt = bufY;
-    static_for<0, NUM_OUT - 1>([&](auto kc) {
+    static_for<0, NH>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
       hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur);
       const f32x16& bk = bo_r[k];
@@ -339,32 +347,49 @@ __global__ __launch_bounds__(256) void node_out_res_kernel(NodeOutArgs a) {
         hk[k][r] = t[0];
         hk[k][r + 1] = t[1];
       }
-      put(nxt, hk[k]);  // W16A16: hk <- f16(tanh), what the backward multiplies by
-      lds_barrier();
-      _Float16* tmp = cur; cur = nxt; nxt = tmp;
+      if constexpr (k + 1 < NH) {
+        put(nxt, hk[k]);  // W16A16: hk <- f16(tanh), what the next layer and the backward see
+        lds_barrier();
+        _Float16* tmp = cur; cur = nxt; nxt = tmp;
+      } else if (HOUT) {  // the last hidden layer feeds no GEMM: only its fp16 rounding point
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hk[k][r] = (float)(_Float16)hk[k][r];
+      }
     });
-    const f32x16 e = gemm(std::integral_constant<int, 2 + NUM_OUT - 1>{}, cur);
-    if (col0 && ok) a.e_node[row] = e[0];
+    // ---- ... last layer: e = <w_last, h>, this lane's 16 columns, then the other half of the wave; the four waves'
+    //      parts meet in LDS behind the next barrier
+    {
+      float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        e0 = __builtin_fmaf(wl[r], hk[NH - 1][r], e0);
+        e1 = __builtin_fmaf(wl[r + 1], hk[NH - 1][r + 1], e1);
+      }
+      const float e = fmd_xor32_sum(e0 + e1);
+      if (h == 0) e_part[par][w][nl] = e;
+    }
+    // ---- output network backward: dE/de = 1, so dE/d(pre-activation of the last hidden layer) = w_last (1 - h^2)
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = wl[r] * (1.0f - hk[NH - 1][r] * hk[NH - 1][r]);
+    put(nxt, g);  // W16A16: f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
+    lds_barrier();
+    { _Float16* tmp = cur; cur = nxt; nxt = tmp; }
+    if (w == 0 && h == 0 && ok)
+      a.e_node[row] = ((e_part[par][0][nl] + e_part[par][1][nl]) + e_part[par][2][nl]) + e_part[par][3][nl];
     {  // The next tile's rows are requested HERE: behind the only conditional store of the tile (what is older than a
-       // request does not enter the count of operations the wait for it may leave outstanding) and three stages
-       // ahead of their use.  Past the last tile: the last tile again, unused.
+       // request does not enter the count of operations the wait for it may leave outstanding) and the remaining
+       // backward stages ahead of their use.  Past the last tile: the last tile again, unused.
       const int64_t nx = next < n_tiles ? next : n_tiles - 1;
       rows_fetch<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, nx * 32, a.n_nodes, tid);
       xo = load_cols(a.x, nx * 32 + nl, a.n_nodes, w, h);
     }
-    // ---- output network backward: dE/de = 1 in column 0
-    f32x16 g = zero16();
-    if (col0) g[0] = 1.0f;
-    put(nxt, g);
-    lds_barrier();
-    { _Float16* tmp = cur; cur = nxt; nxt = tmp; }
-    static_for<0, NUM_OUT - 1>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;   // operand pot[NUM_OUT-1-j], multiplies by 1 - hk[NUM_OUT-2-j]^2
-      constexpr int k = NUM_OUT - 1 - j;
-      g = gemm(std::integral_constant<int, 2 + NUM_OUT + j>{}, cur);
+    static_for<0, NH - 1>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;   // operand pot[NH-1-j], then times 1 - hk[NH-2-j]^2
+      g = gemm(std::integral_constant<int, 2 + NH + j>{}, cur);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[k - 1][r] * hk[k - 1][r];
-      put(nxt, g);  // W16A16: f16(g (1 - y^2)) before the dot (cfconv_kernels.py:1019-1023)
+      for (int r = 0; r < 16; ++r) g[r] *= 1.0f - hk[NH - 2 - j][r] * hk[NH - 2 - j][r];
+      put(nxt, g);
       lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
