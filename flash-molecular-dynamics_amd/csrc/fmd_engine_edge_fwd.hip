@@ -36,6 +36,11 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
+  // DB (W16A16, whole-aggregate mode): the hidden tile is ONE fp16 plane, so the region holds two of them and the
+  // tile is double-buffered -- the producers write tile t+S into the plane the consumers are not reading, and ONE barrier
+  // per tile ("tile t+S visible, tile t consumed") replaces the pair A / B: with a third of the MFMA work the two
+  // barriers and the serial put between them were a fifth of the tile.
+  constexpr bool DB = HALF && !FS && !SH;
   float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
   float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -147,13 +152,14 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(hh[q]), "+v"(hl[q]));
       };
-      auto put = [&]() {
+      auto put_to = [&](_Float16* plane) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
+          *reinterpret_cast<f16x4*>(plane + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
           if (!HALF) *reinterpret_cast<f16x4*>(hid_lo + c32 * LDH + 32 * w + 8 * q + 4 * h) = hl[q];
         }
       };
+      auto put = [&]() { put_to(hid_hi); };
       // SH: the Gaussians of a tile are formed ONCE per workgroup, k-step w by producer wave w, as split fragments in
       // LDS.  The consumers' chain (L1 + aggregate update) is the longer one between A and B, so the producers form
       // the fragments of the tile after next in the time they would wait for B (d_n holds that tile's distances once
@@ -193,6 +199,17 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       put();
       __syncthreads();  // A(first)
       FMD_MARK(11)
+      if constexpr (DB) {
+        int par = 1;
+        for (int t = T0; t < t_end; t += S, par ^= 1) {
+          compute(t + 2 * S);  // tile t+S, while the consumers work on tile t ...
+          FMD_MARK(0)
+          put_to(par ? hid_lo : hid_hi);  // ... into the plane they are not reading
+          FMD_MARK(2)
+          __syncthreads();     // tile t+S visible, tile t consumed
+          FMD_MARK(3)
+        }
+      } else {
       for (int t = T0; t < t_end; t += S) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
         if (SH) gauss();     // tile t+2S
@@ -204,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         FMD_MARK(2)
         __syncthreads();     // A(t+S)
         FMD_MARK(3)
+      }
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
@@ -302,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       f32x16 fl_prev = zero16();
       __syncthreads();  // A(first)
       FMD_MARK(11)
-      for (int t = T0; t < t_end; t += S) {
+      int par = 0;   // DB: plane that holds tile t
+      for (int t = T0; t < t_end; t += S, par ^= 1) {
         // Order inside the A-B window: the update of tile t-S first, L1 of tile t second.  After barrier A the producer
         // that shares this SIMD starts with the 12 MFMAs of the next tile's layer 0; with L1 in front the two bursts
         // met on the matrix pipe.  The update (VALU / LDS / gathers) runs under that burst, and L1 under the producer's
@@ -353,12 +372,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           });
         }
         FMD_MARK(0)
+        if (DB) fetch_meta(t + S);  // (the list registers are free once X is refilled; there is no B-A window in this form)
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
         {
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
-          const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
+          const _Float16* ph = (DB && par ? hid_lo : hid_hi) + c32 * LDH + 8 * h;
           const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
           f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
           f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
@@ -379,12 +399,14 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r];
         asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
         FMD_MARK(2)
-        __syncthreads();  // B(t): hidden tiles consumed
+        __syncthreads();  // B(t): hidden tiles consumed (DB: and tile t+S visible)
         FMD_MARK(3)
-        fetch_meta(t + S);  // (in the window where the producers write the next tile: the consumers have nothing else there)
-        FMD_MARK(4)
-        __syncthreads();  // A(t+S)
-        FMD_MARK(5)
+        if (!DB) {
+          fetch_meta(t + S);  // (in the window where the producers write the next tile: the consumers have nothing else there)
+          FMD_MARK(4)
+          __syncthreads();  // A(t+S)
+          FMD_MARK(5)
+        }
       }
       message(fl_prev);  // last tile
       }

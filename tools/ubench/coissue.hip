@@ -12,8 +12,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define REP4(x) x x x x
 #define REP8(x) x x x x x x x x
 
-enum Role { IDLE = 0, MFMA = 1, VALU = 2, MIX = 3, LDSRW = 4, TRANS = 5, PKV = 6, MIX3 = 7, CVT = 8, MIXF = 9, CVTS = 10, PKMUL = 11, PERM = 12, SWAP = 13 };
+enum Role { IDLE = 0, MFMA = 1, VALU = 2, MIX = 3, LDSRW = 4, TRANS = 5, PKV = 6, MIX3 = 7, CVT = 8, MIXF = 9, CVTS = 10, PKMUL = 11, PERM = 12, SWAP = 13, GATH = 14, LDSB = 15 };
 
+__device__ const float* g_table;   // [N][128] fp32, the gather role's rows
 // one "unit" of each role ~ 8 MFMAs (256 pipe cycles) or 64 VALU (256 issue cycles)
 template <int role>
 __device__ __forceinline__ void run_role(int iters, float& a0, float& a1, float& a2, float& a3,
@@ -74,6 +75,22 @@ __device__ __forceinline__ void run_role(int iters, float& a0, float& a1, float&
            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc1, 0, 0, 0);
            asm volatile("v_fma_f32 %0, %0, %0, 1.0\n v_fma_f32 %1, %1, %1, 1.0\n v_fma_f32 %2, %2, %2, 1.0\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (role == GATH) {  // 32 row gathers (global_load_dword, lanes 0-31 one 128-byte row segment, lanes 32-63 another)
+      float v[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const unsigned row = ((unsigned)(it * 32 + k) * 2654435761u + (lane >> 5) * 40503u) % 269u;
+        v[k] = g_table[(size_t)(blockIdx.x / 2 * 269 + row) * 128 + (lane & 31) + 32 * (threadIdx.x >> 6 & 3)];
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) a0 += v[k];
+    } else if (role == LDSB) {  // 32 ds_read_b128 (fragment reads)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const f4 v = *reinterpret_cast<const f4*>(&lds[((k * 64 + lane) * 4) & 4095]);
+        a0 += v[0] + v[3];
+      }
     } else if (role == LDSRW) {  // 16 ds_read_b32 + 16 fma + 16 ds_write_b32 (the aggregate update pattern)
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -191,6 +208,12 @@ void run(const char* name) {
 
 int main() {
   hipMalloc(&d, nblk * 16 * sizeof(unsigned long long));
+  {
+    float* t;
+    hipMalloc(&t, (size_t)34432 * 128 * 4);
+    hipMemset(t, 0, (size_t)34432 * 128 * 4);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_table), &t, sizeof(t));
+  }
   // per 64 iterations: MFMA = 512 MFMA; VALU = 4096 v_fma; MIX = 512 MFMA + 2560 v_fma; MIX3 = 512 + 1536;
   // TRANS = 2048 v_exp + 2048 v_fma; PKV = 4096 v_pk_fma; LDSRW = 1024 (ds_read, fma, ds_write)
   run<MFMA, IDLE>("MFMA alone (waves 0-3)");
@@ -227,6 +250,17 @@ int main() {
   run<MFMA, LDSRW>("older MFMA | younger LDSRW");
   run<LDSRW, VALU>("older LDSRW | younger VALU");
   run<LDSRW, LDSRW>("LDSRW | LDSRW");
+  // row gathers (32 per iteration) and 16-byte LDS fragment reads (32 per iteration) beside the other wave's work
+  run<GATH, IDLE>("GATH alone (waves 0-3)");
+  run<GATH, MFMA>("older GATH | younger MFMA");
+  run<MFMA, GATH>("older MFMA | younger GATH");
+  run<GATH, VALU>("older GATH | younger VALU");
+  run<VALU, GATH>("older VALU | younger GATH");
+  run<GATH, GATH>("GATH | GATH");
+  run<LDSB, IDLE>("LDSB alone");
+  run<LDSB, MFMA>("older LDSB | younger MFMA");
+  run<MFMA, LDSB>("older MFMA | younger LDSB");
+  run<LDSB, VALU>("older LDSB | younger VALU");
   // 16 waves (4 per SIMD): per 64 iterations M16 = 1024 MFMA 16x16x32, V16 = 4096 v_fma, X16 = 1024 MFMA + 3072 v_fma
   run16h<M16, I16, I16, I16>("16w: M16 alone");
   run16h<M16, M16, I16, I16>("16w: M16 M16");
