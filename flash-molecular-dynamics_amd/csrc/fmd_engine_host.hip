@@ -115,8 +115,23 @@ int device_cus() {
 }
 // `cus`: the device's CU count at launch; MAX_CUS when SIZING a workspace (the split falls with the CU count, so the
 // size computed for MAX_CUS covers every device: fmd_schnet_workspace_bytes is device independent)
+constexpr int TAIL_MAX_SPLIT = 4;  // batches larger than the chip: workgroups per molecule tried against the tail
 int resolve_split(const fmd_schnet_desc* d, int64_t n_mol, int cus) {
   if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
+  if (n_mol > cus) {
+    // More molecules than CUs: the hardware deals workgroups to CUs as they free up, and what is lost is the tail --
+    // 384 molecules on 256 CUs keep half the chip idle for the second half of the launch.  Cutting every molecule into
+    // S pieces (static interleave of its tiles) makes the pieces finer than the tail: the launch lasts
+    // ceil(n_mol S / cus) / S molecule-times, plus a few per cent per extra piece for its aggregate (zeroing, flush,
+    // one more slab for the node kernels to add).  384 molecules: S = 2 -> 1.5 instead of 2; 512: S = 1 (2.0 either way).
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= TAIL_MAX_SPLIT; ++s) {
+      const double t = (double)((n_mol * s + cus - 1) / cus) / s * (1.0 + 0.04 * (s - 1));
+      if (t < best_t - 1e-9) { best_t = t; best = s; }
+    }
+    return best;
+  }
   // as many workgroups per molecule as fit the chip in ONE round (floor, not ceil: 100 molecules x 3 would take a second
   // round for 44 workgroups -- 0.67 of a molecule's tiles per CU against 0.5 with x 2 -- and only a launch of one round
   // gets the balanced work items)
@@ -282,7 +297,10 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
                                               int64_t n_nodes, int64_t max_pairs_per_mol) {
   if (!desc_ok(desc) || n_mol < 0 || n_nodes < 0 || max_pairs_per_mol < 0) return FMD_EINVAL;
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
-  const int split = resolve_split(desc, n_mol, MAX_CUS);  // the slabs scale with it; >= 2 for the feature-split mode
+  // the slabs scale with the split: the largest any device can choose (a partition with fewer CUs than molecules may
+  // cut the molecules into up to TAIL_MAX_SPLIT pieces); >= 2 for the feature-split mode
+  int split = resolve_split(desc, n_mol, MAX_CUS);
+  if (desc->n_split == 0 && split < TAIL_MAX_SPLIT) split = TAIL_MAX_SPLIT;
   return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
 }
 

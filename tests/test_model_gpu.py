@@ -647,6 +647,48 @@ def test_balanced_schedule_extreme_batches(params, shape):
     assert r_e < 1e-4 and r_f < 1e-4, (r_e, r_f)
 
 
+def test_batch_larger_than_the_chip_is_cut_against_the_tail(params):
+    """384 molecules on 256 CUs: one workgroup per molecule keeps half the chip idle for the second half of every pair
+    launch, so the library cuts each molecule into two pieces (csrc/fmd_engine_host.hip resolve_split).  Same energies
+    and forces as one piece per molecule up to the regrouping of fp32 partial sums, oracle parity on three molecules,
+    and -- printed -- the time of both."""
+    import time
+
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    B, A = 384, 120
+    pos, types, ptr = so.synth_batch(B, A, 5.0)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    model = S.model_from_params(params).to(DEV)
+    auto, one = engine.FusedSchNetEngine(model), engine.FusedSchNetEngine(model, n_split=1)
+    e_a, f_a = auto.energy_forces(P, T, Q, A)
+    e_1, f_1 = one.energy_forces(P, T, Q, A)
+    assert int(auto.status[0]) == 0 and int(one.status[0]) == 0 and int(auto.status[2]) == int(one.status[2])
+    re = float((e_a - e_1).abs().max() / e_1.abs().max())
+    rf = float((f_a - f_1).norm() / f_1.norm())
+    assert re < 2e-6 and rf < 2e-6, (re, rf)
+    e_b, f_b = auto.energy_forces(P, T, Q, A)
+    assert torch.equal(e_a, e_b) and torch.equal(f_a, f_b)          # repeat calls: the same bits
+    for m in (0, 255, 383):
+        sl = slice(m * A, (m + 1) * A)
+        e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sl].double(), types[sl],
+                                           torch.tensor([0, A]))
+        r_e, r_f = _relerr(e_a[m:m + 1], f_a[sl], e_o.numpy(), f_o.numpy())
+        assert r_e < 1e-4 and r_f < 1e-4, (m, r_e, r_f)
+    t = {}
+    for name, eng in (("two pieces per molecule", auto), ("one piece per molecule", one)):
+        for _ in range(3):
+            eng.energy_forces(P, T, Q, A)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.energy_forces(P, T, Q, A)
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) / 20
+    print("384 x 120 beads: " + ", ".join(f"{k} {1e3 * v:.3f} ms" for k, v in t.items()))
+
+
 def test_balanced_schedule_matches_static_schedule(params):
     """128 molecules of very different sizes (60..269 beads): with 128 x 2 workgroups on 256 CUs the pair kernels run the
     balanced work items of sched_body (large molecules hand their surplus tiles, with an extra slab, to the last
