@@ -5,9 +5,10 @@ Replaces, for qualifying models, what the reference does per timestep in SchNet.
 GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model
 qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
 <= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
-tanh, hidden = filters = 128, a 2- or 3-linear output MLP with widths <= 128, fp32 weights (or the
-W16A16 twins of models/gptq.py on both the filter and the output networks), and no molecule larger
-than 535 beads (up to 283 a molecule's aggregate fits one workgroup's LDS; up to 535 the engine
+tanh, hidden <= 128 and filters <= 128 (the kernels are built for 128 x 128: narrower layers are zero-padded when the
+weights are packed, which is exact -- a padded feature is 0 in every layer -- and costs the padded arithmetic), a 2- or
+3-linear output MLP with widths <= 128, fp32 weights (or the W16A16 twins of models/gptq.py on both the filter and
+the output networks), and no molecule larger than 535 beads (up to 283 a molecule's aggregate fits one workgroup's LDS; up to 535 the engine
 switches to its feature-split mode, two workgroups holding 64 features each).  Anything else returns
 None here and GradientsOut uses the operator path.
 """
@@ -30,6 +31,24 @@ STATUS_CHECK_EVERY = 1024      # force evaluations between two reads of the devi
 
 def _linears(mlp):
     return [m for m in mlp.layers if isinstance(m, torch.nn.Linear)]
+
+
+WIDTH = 128   # hidden = filters of the kernels (csrc/fmd_engine.h F)
+
+
+def _pad(t, rows=None, cols=None):
+    """fp32 host copy of a weight matrix / bias zero-padded to [rows, cols] / [rows] (None: keep)."""
+    t = t.detach().to("cpu", torch.float32)
+    shape = list(t.shape)
+    if rows is not None:
+        shape[0] = rows
+    if cols is not None and t.dim() == 2:
+        shape[1] = cols
+    if shape == list(t.shape):
+        return t.contiguous()
+    out = torch.zeros(shape, dtype=torch.float32)
+    out[tuple(slice(0, n) for n in t.shape)] = t
+    return out
 
 
 def _filter_weights(fn):
@@ -82,14 +101,19 @@ class FusedSchNetEngine:
             if not isinstance(blk.activation, torch.nn.Tanh):
                 raise ValueError("fused engine: tanh activation required")
         filt = [_filter_weights(blk.conv.filter_network) for blk in blocks]
-        for f0_w, f0_b, f1_w, _ in filt:
-            if tuple(f0_w.shape) != (128, rbf.num_rbf) or tuple(f1_w.shape) != (128, 128):
-                raise ValueError("fused engine: filter network must be Linear(R,128)+tanh+Linear(128,128,no bias)")
-        if hidden != 128:
-            raise ValueError("fused engine: hidden = filters = 128 required")
+        n_filters = int(filt[0][0].shape[0])
+        if hidden > WIDTH or n_filters > WIDTH or hidden < 1 or n_filters < 1:
+            raise ValueError(f"fused engine: hidden ({hidden}) and filters ({n_filters}) must be <= {WIDTH}")
+        for (f0_w, f0_b, f1_w, _), blk in zip(filt, blocks):
+            if tuple(f0_w.shape) != (n_filters, rbf.num_rbf) or tuple(f1_w.shape) != (n_filters, n_filters) \
+                    or tuple(blk.conv.lin1.weight.shape) != (n_filters, hidden) \
+                    or tuple(blk.conv.lin2.weight.shape) != (hidden, n_filters) \
+                    or tuple(blk.lin.weight.shape) != (hidden, hidden):
+                raise ValueError("fused engine: a block must be lin1(hidden, filters) / Linear(R, filters)+tanh+"
+                                 "Linear(filters, filters, no bias) / lin2(filters, hidden) / lin(hidden, hidden)")
         outs, out_half = _output_weights(model.output_network)
         if len(outs) not in (2, 3) or outs[-1][0].shape[0] != 1 or outs[-1][1] is not None \
-                or any(w_.shape[0] > 128 for w_, _ in outs) or outs[0][0].shape[1] != 128:
+                or any(w_.shape[0] > 128 for w_, _ in outs) or outs[0][0].shape[1] != hidden:
             raise ValueError("fused engine: output MLP must have 2-3 linears, widths <= 128, last -> 1 without bias")
         halves = [q for *_, q in filt] + [out_half]
         if any(halves):
@@ -121,17 +145,22 @@ class FusedSchNetEngine:
             keep.append(h)
             return ctypes.c_void_p(h.data_ptr())
 
+        # narrower layers are zero-padded to the kernels' 128 x 128: a padded feature is exactly 0 everywhere (zero
+        # embedding column -> zero lin1 row -> tanh(0 + 0) = 0 in the filter -> zero message -> zero lin2 / lin rows and
+        # biases), so energies and forces are those of the unpadded model
         bw = (_ffi.SchnetBlockWeights * len(blocks))()
         for l, blk in enumerate(blocks):
-            bw[l].lin1_w = host(blk.conv.lin1.weight)
-            bw[l].f0_w, bw[l].f0_b, bw[l].f1_w = host(filt[l][0]), host(filt[l][1]), host(filt[l][2])
-            bw[l].lin2_w, bw[l].lin2_b = host(blk.conv.lin2.weight), host(blk.conv.lin2.bias)
-            bw[l].lin_w, bw[l].lin_b = host(blk.lin.weight), host(blk.lin.bias)
+            bw[l].lin1_w = host(_pad(blk.conv.lin1.weight, WIDTH, WIDTH))
+            bw[l].f0_w = host(_pad(filt[l][0], WIDTH, None))
+            bw[l].f0_b = host(_pad(filt[l][1], WIDTH))
+            bw[l].f1_w = host(_pad(filt[l][2], WIDTH, WIDTH))
+            bw[l].lin2_w, bw[l].lin2_b = host(_pad(blk.conv.lin2.weight, WIDTH, WIDTH)), host(_pad(blk.conv.lin2.bias, WIDTH))
+            bw[l].lin_w, bw[l].lin_b = host(_pad(blk.lin.weight, WIDTH, WIDTH)), host(_pad(blk.lin.bias, WIDTH))
         w = _ffi.SchnetWeights()
-        w.embedding = host(model.embedding_layer.weight)
+        w.embedding = host(_pad(model.embedding_layer.weight, None, WIDTH))
         w.blocks = ctypes.cast(bw, ctypes.POINTER(_ffi.SchnetBlockWeights))
         for k, (ow, ob) in enumerate(outs):
-            w.out_w[k] = host(ow)
+            w.out_w[k] = host(_pad(ow, None, WIDTH) if k == 0 else ow)
             w.out_b[k] = host(ob) if ob is not None else None
         centers = host(rbf.offset)
         nbytes = _ffi.lib().fmd_schnet_pack_bytes(ctypes.byref(d))
@@ -153,7 +182,7 @@ class FusedSchNetEngine:
         """Engine from a ``state_dict`` keyed by the reference's parameter names (a dict, an ``.npz`` or a
         weights-only ``torch.load`` file; ``prefix=None`` finds the SchNet inside a ``GradientsOut`` / ``SumOut``
         container; ``cutoff``: see ``schnet.model_from_state_dict`` -- hyper-parameters the weights do not encode).
-        Raises ValueError when the model is outside the engine's envelope (hidden = filters = 128,
+        Raises ValueError when the model is outside the engine's envelope (hidden, filters <= 128,
         2 <= num_rbf <= 64, 2-3 output linears)."""
         from .schnet import model_from_state_dict
 

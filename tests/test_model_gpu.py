@@ -647,6 +647,57 @@ def test_balanced_schedule_extreme_batches(params, shape):
     assert r_e < 1e-4 and r_f < 1e-4, (r_e, r_f)
 
 
+def _oracle_params(model, num_rbf, rc):
+    """flat weight dict of oracle/schnet_oracle.py from a host-mirror StandardSchNet"""
+    lin = lambda seq: [m for m in seq if isinstance(m, torch.nn.Linear)]  # noqa: E731
+    p = {"hidden": model.embedding_layer.embedding_dim, "filters": model.interaction_blocks[0].conv.lin1.out_features,
+         "num_rbf": num_rbf, "cutoff": rc, "emb": model.embedding_layer.weight.detach().cpu(), "blocks": [], "out": []}
+    for blk in model.interaction_blocks:
+        fl = lin(blk.conv.filter_network.layers)
+        p["blocks"].append({k: v.detach().cpu() for k, v in dict(
+            lin1_w=blk.conv.lin1.weight, f0_w=fl[0].weight, f0_b=fl[0].bias, f1_w=fl[1].weight,
+            lin2_w=blk.conv.lin2.weight, lin2_b=blk.conv.lin2.bias, lin_w=blk.lin.weight, lin_b=blk.lin.bias).items()})
+    for m in lin(model.output_network.layers):
+        p["out"].append({"w": m.weight.detach().cpu(), "b": None if m.bias is None else m.bias.detach().cpu()})
+    return p
+
+
+@pytest.mark.parametrize("hidden,filters,num_rbf,widths", [(64, 64, 50, [64]), (96, 48, 20, [128, 32]), (128, 32, 64, [16])])
+def test_narrower_models_run_on_the_engine_by_zero_padding(hidden, filters, num_rbf, widths):
+    """StandardSchNet takes any hidden_channels / num_filters (reference models/schnet.py:778-841).  The kernels are
+    built for 128 x 128; layers up to that width are zero-padded when the weights are packed, which is exact.  Engine
+    (through GradientsOut) against the fp64 oracle of the UNPADDED model, fp32 and W16A16."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+    from flashmd_amd.gptq import apply_gptq_w16a16_to_model
+
+    torch.manual_seed(hidden + filters)
+    rc = 5.0
+    model = S.StandardSchNet(S.GaussianBasis(S.CosineCutoff(0.0, rc), num_rbf), S.CosineCutoff(0.0, rc), widths,
+                             hidden_channels=hidden, num_filters=filters, embedding_size=30, num_interactions=2)
+    with torch.no_grad():
+        for n_, prm in model.named_parameters():
+            if n_.endswith("bias"):
+                prm.uniform_(-0.1, 0.1)
+    pos, types, ptr = so.synth_batch(3, 90, rc)
+    p64 = so.params_to(_oracle_params(model, num_rbf, rc), torch.float64)
+    e_o, f_o = so.schnet_energy_forces(p64, pos.double(), types, ptr)
+    model = model.to(DEV).eval()
+    S.USE_FUSED_ENGINE = True
+    assert engine.maybe_engine(model, S.Batch(pos.to(DEV), types.to(DEV), ptr.to(DEV))) is not None
+    d = S.GradientsOut(model)(S.Batch(pos.to(DEV), types.to(DEV), ptr.to(DEV), max_beads_per_mol=90))
+    re, rf = _relerr(d.out["SchNet"]["energy"], d.out["SchNet"]["forces"], e_o.numpy(), f_o.numpy())
+    print(f"hidden {hidden} filters {filters} R {num_rbf}: engine energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-4 and rf < 1e-4 and rf < 2e-5
+    # the same model in W16A16 (engine precision override): inside the W16A16 band of the oracle
+    e_w, f_w = so.schnet_energy_forces(_oracle_params(model.cpu(), num_rbf, rc), pos, types, ptr, w16a16=True)
+    eng = engine.FusedSchNetEngine(model.to(DEV), precision="w16a16")
+    e16, f16 = eng.energy_forces(pos.to(DEV), types.to(DEV), ptr.to(DEV), 90)
+    re, rf = _relerr(e16, f16, e_w.numpy(), f_w.numpy())
+    print(f"   W16A16 vs the W16A16 oracle: energy {re:.2e} forces {rf:.2e}")
+    assert re < 2e-3 and rf < 2e-3
+
+
 def test_batch_larger_than_the_chip_is_cut_against_the_tail(params):
     """384 molecules on 256 CUs: one workgroup per molecule keeps half the chip idle for the second half of every pair
     launch, so the library cuts each molecule into two pieces (csrc/fmd_engine_host.hip resolve_split).  Same energies
