@@ -430,24 +430,25 @@ def main():
     n_settle = leg.settle(args.settle_seconds)
     pairs_start = eng.check_status()[2]   # workload at the start of the timed region
 
-    # ---- the timed region (`value`), then N_REGIONS - 1 back-to-back repeats of it when it is short
+    # ---- the timed region (`value`), then N_REGIONS - 1 back-to-back repeats of it when it is short.  Nothing happens
+    #      between two regions but their barrier + synchronize brackets (every region has its own event handles; status
+    #      words and event times are read after the last one): a host-side pause of a few milliseconds is enough for the
+    #      GPU to drop its clocks, and the region behind it then reads 3-4 % slow.
     n_dom = len(leg.dom_slots)
-    events = HipEvents(2 * n_dom * args.steps)
+    n_regions = N_REGIONS if (args.steps < 200 and not args.pt) else 1
+    events = [HipEvents(2 * n_dom * args.steps) for _ in range(n_regions)]
     attempts = attempt_steps(args.steps, args.exchange_interval) if exchange is not None else []
     tenth = args.steps // 10 if args.steps >= 200 else 0   # sustained-rate marks (runs of >= 200 steps)
-    elapsed, marks, t_exchange, n_exchange = leg.timed_region(args.steps, events, exchange, attempts,
+    elapsed, marks, t_exchange, n_exchange = leg.timed_region(args.steps, events[0], exchange, attempts,
                                                               args.reset_every, tenth)
-    elapsed = max_over_ranks(elapsed)
+    regions_s = [elapsed]
+    for r in range(1, n_regions):
+        regions_s.append(leg.timed_region(args.steps, events[r], None, (), args.reset_every, 0)[0])
+    regions_ms = [1e3 * max_over_ranks(v) / args.steps for v in regions_s]
+    elapsed = regions_ms[0] * args.steps / 1e3
     assert torch.isfinite(sim.x).all() and torch.isfinite(sim.f).all(), "simulation diverged"
     n_pairs = eng.check_status()[2]
-    dom_ms = leg.dominant_ms(events, args.steps) if rank == 0 else 0.0
-    regions_ms = [1e3 * elapsed / args.steps]
-    if args.steps < 200 and not args.pt:
-        for _ in range(N_REGIONS - 1):
-            e_r = max_over_ranks(leg.timed_region(args.steps, events, None, (), args.reset_every, 0)[0])
-            regions_ms.append(1e3 * e_r / args.steps)
-        assert torch.isfinite(sim.f).all(), "simulation diverged"
-        eng.check_status()
+    dom_ms = leg.dominant_ms(events[0], args.steps) if rank == 0 else 0.0
 
     # the same loop with the engine called directly (no GradientsOut / Batch in between), reported beside the line
     direct_ms = None
@@ -569,7 +570,8 @@ def main():
                          "launches_per_step": leg.launches[leg.dom]},
             "timed_regions_ms_per_step": [round(v, 5) for v in regions_ms],
             "timed_regions_note": (f"{len(regions_ms)} back-to-back repeats of the timed region ({args.steps} steps each, "
-                                   "each between its own barrier + synchronize brackets); the first is `value`"),
+                                   "each between its own barrier + synchronize brackets, nothing else in between); the "
+                                   "first is `value`; directed_edges_at_start_and_end span all of them"),
             "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw.items()},
             "kernel_ms_per_step": {n: round(v, 4) for n, v in per_step.items()},
             "kernel_ms_per_step_bracketed": {n: round(v, 4) for n, v in per_step_raw.items()},
