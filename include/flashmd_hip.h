@@ -32,7 +32,9 @@ extern "C" {
 #define FMD_ENONFINITE (-5) /* a force contribution was Inf / NaN / >= 2^31 (reported in the sticky status word) */
 
 const char* fmd_strerror(int code);
-/* ABI version of this library (bumped on any signature change). */
+/* ABI version of this library (bumped on any change a caller can observe).
+ *   3: status word 3 of fmd_schnet_energy_forces is sticky and must be zeroed by the caller; FMD_ENONFINITE;
+ *      fmd_schnet_workspace_bytes no longer depends on the current device (same signatures as 2). */
 int fmd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
