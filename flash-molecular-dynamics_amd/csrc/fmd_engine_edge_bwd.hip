@@ -66,6 +66,13 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   // gW(t+1) and the Gaussians of t+2" from "the producers stage k(t+1) and run the u GEMM of t" -- instead of the four
   // phases the single tile region forces on the other blocks (the producers there wait ~15 % of the tile).
   constexpr bool PIPE = !NEED_GX1 && SHARE && !FS;
+  // TWOB (W16A16, whole-aggregate mode, blocks with a gx1 aggregate): the hidden tile and the gW image are ONE fp16
+  // plane each (8.5 + 8 KB), so they lie side by side in the tile region instead of sharing it, and two of the four
+  // barriers go: "hidden consumed" before the gW store (B) and "gW consumed" before the next hidden tile is put (D) only
+  // existed because the stores overwrote what the other role was reading.  A: hidden(t) visible, gW(t-S) consumed,
+  // partial sums visible.  C: gW(t) visible, hidden(t) consumed.
+  constexpr bool TWOB = HALF && NEED_GX1 && SHARE && !FS;
+  char* const gw_base = reinterpret_cast<char*>(smem) + (TWOB ? 32 * LDH * 2 : 0);
   float* frag_l2 = gx1;                                          // PIPE: second fragment buffer
   float* gw_img2f = frag_l2 + a.nb * 256;                        // PIPE: second gW image (2 planes, 16 KB)
   float* red2 = gw_img2f + 4096;                                 // PIPE: second [4][32] partial sums
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       // gW hand-over image (see gw_row_off): this lane's two read addresses of k-step 0 in the 16-lane group scheme of
       // ds_read_b64_tr_b16 -- lane 4q+p of a group addresses row (feature) f0 + q, pairs 16 g + 4p .. + 3
       const int tg = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
-      const char* gw_img = reinterpret_cast<const char*>(hid_hi);
+      const char* gw_img = gw_base;
       const gw_lds_ptr gw_a1 = gw_lds(gw_img + gw_row_off(16 * ku0 + 8 * h + tq, 4 * tg + tp));
       const gw_lds_ptr gw_a2 = gw_lds(gw_img + gw_row_off(16 * ku0 + 8 * h + 4 + tq, 4 * tg + tp));
       // meta of the tile to stage next (lane = pair view)
@@ -312,24 +319,31 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       auto tile = [&](int t, KSet& cu, KSet& nx) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S, nx);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
-        __syncthreads();     // B(t)
+        if (!TWOB) __syncthreads();     // B(t)
         FMD_MARK(1)
-        __syncthreads();     // C(t): gW(t) visible
+        __syncthreads();     // C(t): gW(t) visible (TWOB: and hidden(t) consumed)
         FMD_MARK(2)
+        if (TWOB) put();     // hidden tile of t+S into its own plane, which the consumers have left
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features); dE/dd = C sum_h u (1-h^2) z' + C' sum_h u h
         const float tot = u_gemm_reduce(gw_a1, gw_a2, cu);
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_MARK(3)
-        __syncthreads();     // D(t): gW consumed, partial sums visible
-        FMD_MARK(4)
-        if (w == 0 && h == 0) {
+        if (!TWOB) {
+          __syncthreads();     // D(t): gW consumed, partial sums visible
+          FMD_MARK(4)
+          if (w == 0 && h == 0) {
+            const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
+            pgd[t * 32 + c32] = FIRST ? sum : cu.gd + sum;
+          }
+          put();               // hidden tiles of t+S
+        }
+        FMD_MARK(5)
+        __syncthreads();     // A(t+S) (TWOB: also gW(t) consumed, partial sums visible)
+        FMD_MARK(6)
+        if (TWOB && w == 0 && h == 0) {   // (red is next written after C(t+S), which this wave reaches after the read)
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
           pgd[t * 32 + c32] = FIRST ? sum : cu.gd + sum;
         }
-        put();               // hidden tiles of t+S
-        FMD_MARK(5)
-        __syncthreads();     // A(t+S)
-        FMD_MARK(6)
       };
       for (int t = T0; t < t_end; t += 2 * S) {
         tile(t, ks_a, ks_b);
@@ -594,9 +608,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         fetch_meta(t + 2 * S);
         FMD_MARK(6)
         }
-        __syncthreads();  // B(t): hidden tiles consumed
+        if (!TWOB) __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(2)
-        gw_store(reinterpret_cast<char*>(hid_hi));
+        gw_store(gw_base);
         FMD_MARK(3)
         __syncthreads();  // C(t): gW visible
         FMD_MARK(4)
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (SHARE) share_fragments();
         form_gw();  // tile t+S
         FMD_MARK(7)
-        __syncthreads();  // D(t)
+        if (!TWOB) __syncthreads();  // D(t)
         FMD_MARK(8)
         __syncthreads();  // A(t+S)
         FMD_MARK(9)
