@@ -82,9 +82,12 @@ def parse(argv=None):
                          "steps (inside the timed region): a long run then repeats the specified workload instead of "
                          "following the synthetic system's relaxation; 0 = never (the default)")
     ap.add_argument("--settle-seconds", type=float, default=0.75,
-                    help="untimed force evaluations at fixed positions for this long (on top of --warmup) before the "
-                         "timed region: a GPU that has just been woken holds lower clocks for the first tenths of a "
-                         "second; 0 = none")
+                    help="untimed timesteps of the timed loop for about this long (on top of --warmup), running straight "
+                         "into the timed region's opening bracket: after any idle gap of >= 2 ms the next ~20 steps run "
+                         "7-10 %% slow while the clocks ramp (tools/clock_timeline.py); 0 = none")
+    ap.add_argument("--no-filter-stash", action="store_true",
+                    help="FMD_FLAG_NO_FILTER_STASH: the backward pair kernels recompute filter layer 1 instead of reading "
+                         "the forward kernels' values back (A/B of the stash; same results)")
     ap.add_argument("--pt", action="store_true", help="parallel tempering (BASELINE configs[4])")
     ap.add_argument("--exchange-interval", type=int, default=100, help="reference examples/parallel_tempering.yaml:11")
     ap.add_argument("--pt-betas", type=int, default=8, help="temperatures in the batch when --pt runs on one GPU")
@@ -204,7 +207,8 @@ class Leg:
         """state = (pos, types, ptr, masses, beta) on the device"""
         self.args, self.barrier, self.precision = args, barrier, precision
         pos, types, ptr, masses, beta = state
-        self.eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")), precision=precision)
+        self.eng = engine.FusedSchNetEngine(model, n_split=int(os.environ.get("FMD_NSPLIT", "0")), precision=precision,
+                                            filter_stash=not args.no_filter_stash)
         self.names = self.eng.kernel_names()
         self.nk = len(self.names)
         # the reference-shaped entry point: GradientsOut(model)(batch) finds the engine on the model; one collated
@@ -262,17 +266,36 @@ class Leg:
         self.dom = max(self.prof_ms, key=lambda n: self.prof_ms[n] * self.launches[n])
         self.dom_slots = [k for k, name in enumerate(self.names) if name == self.dom]
 
-    def settle(self, seconds):
-        """untimed force evaluations at the CURRENT positions (nothing is integrated: the synthetic system is not
-        stationary -- its pair count falls by 0.8 % in 500 steps -- so steps here would hand the timed region a
-        lighter workload)"""
-        n, t_s = 0, time.perf_counter()
-        while time.perf_counter() - t_s < seconds:
-            for _ in range(20):
-                self.sim.force_fn(self.sim.x)
-            torch.cuda.synchronize()
-            n += 20
-        return n
+    def save_state(self):
+        sim = self.sim
+        return sim.x.clone(), sim.v.clone(), sim.f.clone(), sim.energy.clone()
+
+    def restore_state(self, st):
+        sim = self.sim
+        sim.x.copy_(st[0]); sim.v.copy_(st[1]); sim.f.copy_(st[2]); sim.energy.copy_(st[3])
+
+    def estimate_ms_per_step(self, n=20):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            self.sim.timestep()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / n
+
+    def settle(self, n_steps, state, every=40):
+        """`n_steps` untimed timesteps of the SAME loop the timed region runs (same kernels, same launch cadence),
+        enqueued without a synchronisation; the state is put back to `state` every `every` steps and at the end, so the
+        timed region starts from the specified workload (the synthetic system sheds pairs while it is integrated).
+        Nothing here waits for the GPU: the region's opening barrier + synchronize is the first wait, and nothing but
+        that bracket sits between the last settle step and the first timed step.  Why it matters
+        (tools/clock_timeline.py, profiles/r04_clock_timeline.txt): after ANY idle gap of >= 2 ms the next ~20 steps run
+        7-10 % slow (1.60-1.67 against 1.49 ms: the clocks ramp), after a gap below a millisecond they do not."""
+        for i in range(n_steps):
+            self.sim.timestep()
+            if (i + 1) % every == 0:
+                self.restore_state(state)
+        self.restore_state(state)
+        return n_steps
 
     def timed_region(self, steps, events, exchange=None, attempts=(), reset_every=0, tenth=0):
         """EXACTLY `steps` timesteps between barrier + synchronize brackets; the dominant kernel's launches are
@@ -338,6 +361,58 @@ def kernel_table(leg, dom_ms, ms_per_step):
     scale = min(1.0, room / others) if others > 0 and room > 0 else 1.0
     per_step = {n: (v if n == leg.dom else v * scale) for n, v in per_step_raw.items()}
     return raw, per_step_raw, per_step, scale
+
+
+def smi_clock():
+    """sclk / socket power as the SMI library reports them, or None (read OUTSIDE the gaps between timed regions: a
+    query takes milliseconds of host time, and an idle gap of that length is itself what makes a region read slow)"""
+    try:
+        import amdsmi
+
+        if not getattr(smi_clock, "h", None):
+            amdsmi.amdsmi_init()
+            smi_clock.h = amdsmi.amdsmi_get_processor_handles()[torch.cuda.current_device()]
+        c = amdsmi.amdsmi_get_clock_info(smi_clock.h, amdsmi.AmdSmiClkType.GFX)
+        p = amdsmi.amdsmi_get_power_info(smi_clock.h)
+        return {"sclk_mhz": c.get("clk"), "socket_power_w": p.get("current_socket_power", p.get("average_socket_power"))}
+    except Exception:  # noqa: BLE001 -- the library is optional
+        return None
+
+
+def measure(leg, steps, n_regions, settle_seconds, max_over_ranks, exchange=None, attempts=(), reset_every=0, tenth=0):
+    """The measurement of one leg: everything that needs the host (status read, event handles, the estimate that turns
+    --settle-seconds into a step count every rank agrees on) happens FIRST; then the settle phase -- the timed loop
+    itself, untimed, state restored -- runs straight into the first region's barrier + synchronize, and the regions
+    follow back to back with nothing but their brackets in between (garbage collection off).  The first region is
+    `value`; the dominant kernel's event times are read for EVERY region afterwards, so a slow region can be
+    attributed to the device or to the host."""
+    import gc
+
+    eng = leg.eng
+    pairs_start = eng.check_status()[2]   # workload at the start of the timed region (the settle phase restores it)
+    n_dom = len(leg.dom_slots)
+    events = [HipEvents(2 * n_dom * steps) for _ in range(n_regions)]
+    state = leg.save_state()
+    est = max_over_ranks(leg.estimate_ms_per_step())
+    leg.restore_state(state)
+    n_settle = int(settle_seconds * 1e3 / est) if settle_seconds > 0 else 0
+    clk0 = smi_clock()
+    leg.barrier()   # ranks leave together (and RCCL's barrier is set up before it brackets a region)
+    gc.collect()
+    gc.disable()
+    try:
+        leg.settle(n_settle, state)
+        out = [leg.timed_region(steps, events[0], exchange, attempts, reset_every, tenth)]
+        for r in range(1, n_regions):
+            out.append(leg.timed_region(steps, events[r], None, (), reset_every, 0))
+    finally:
+        gc.enable()
+    clk1 = smi_clock()
+    regions_ms = [1e3 * max_over_ranks(o[0]) / steps for o in out]
+    return {"regions_ms": regions_ms, "dom_ms": [leg.dominant_ms(ev, steps) for ev in events],
+            "pairs_start": pairs_start, "pairs_end": eng.check_status()[2], "n_settle": n_settle,
+            "marks": out[0][1], "t_exchange": out[0][2], "n_exchange": out[0][3],
+            "smi": {"before_settle": clk0, "after_last_region": clk1}}
 
 
 def main():
@@ -427,36 +502,25 @@ def main():
         exchange(sim)
         bytes_before = getattr(exchange, "bytes_sent", 0)
     leg.profile()
-    n_settle = leg.settle(args.settle_seconds)
-    pairs_start = eng.check_status()[2]   # workload at the start of the timed region
-
-    # ---- the timed region (`value`), then N_REGIONS - 1 back-to-back repeats of it when it is short.  Nothing happens
-    #      between two regions but their barrier + synchronize brackets (every region has its own event handles; status
-    #      words and event times are read after the last one): a host-side pause of a few milliseconds is enough for the
-    #      GPU to drop its clocks, and the region behind it then reads 3-4 % slow.
-    n_dom = len(leg.dom_slots)
     n_regions = N_REGIONS if (args.steps < 200 and not args.pt) else 1
-    events = [HipEvents(2 * n_dom * args.steps) for _ in range(n_regions)]
     attempts = attempt_steps(args.steps, args.exchange_interval) if exchange is not None else []
     tenth = args.steps // 10 if args.steps >= 200 else 0   # sustained-rate marks (runs of >= 200 steps)
-    elapsed, marks, t_exchange, n_exchange = leg.timed_region(args.steps, events[0], exchange, attempts,
-                                                              args.reset_every, tenth)
-    regions_s = [elapsed]
-    for r in range(1, n_regions):
-        regions_s.append(leg.timed_region(args.steps, events[r], None, (), args.reset_every, 0)[0])
-    regions_ms = [1e3 * max_over_ranks(v) / args.steps for v in regions_s]
+    meas = measure(leg, args.steps, n_regions, args.settle_seconds, max_over_ranks, exchange, attempts,
+                   args.reset_every, tenth)
+    regions_ms, dom_regions, n_settle = meas["regions_ms"], meas["dom_ms"], meas["n_settle"]
+    pairs_start, n_pairs, marks = meas["pairs_start"], meas["pairs_end"], meas["marks"]
+    t_exchange, n_exchange = meas["t_exchange"], meas["n_exchange"]
     elapsed = regions_ms[0] * args.steps / 1e3
+    dom_ms = dom_regions[0]
     assert torch.isfinite(sim.x).all() and torch.isfinite(sim.f).all(), "simulation diverged"
-    n_pairs = eng.check_status()[2]
-    dom_ms = leg.dominant_ms(events[0], args.steps) if rank == 0 else 0.0
 
     # the same loop with the engine called directly (no GradientsOut / Batch in between), reported beside the line
     direct_ms = None
     if not args.pt:
         sim.force_fn = leg.force_direct
-        for _ in range(3):
-            sim.timestep()
         k_dir = min(args.steps, 200)
+        for _ in range(max(3, k_dir)):   # (no idle gap in front of this loop either)
+            sim.timestep()
         barrier()
         td = time.perf_counter()
         for _ in range(k_dir):
@@ -494,12 +558,10 @@ def main():
         for _ in range(5):
             lg.sim.timestep()
         lg.profile()
-        p0 = lg.eng.check_status()[2]
-        ev16 = HipEvents(2 * len(lg.dom_slots) * args.w16a16_steps)
-        e16 = lg.timed_region(args.w16a16_steps, ev16)[0]
+        m16 = measure(lg, args.w16a16_steps, N_REGIONS, args.settle_seconds, max_over_ranks)
         assert torch.isfinite(lg.sim.f).all(), "W16A16 simulation diverged"
-        p1 = lg.eng.check_status()[2]
-        d16 = lg.dominant_ms(ev16, args.w16a16_steps)
+        p0, p1, d16 = m16["pairs_start"], m16["pairs_end"], m16["dom_ms"][0]
+        e16 = m16["regions_ms"][0] * args.w16a16_steps / 1e3
         flops16 = 2.0 * (p0 + p1) * 128 * (args.num_rbf + 128)
         ach16 = flops16 / (d16 * 1e-3) / 1e12
         raw16, _, per16, sc16 = kernel_table(lg, d16, 1e3 * e16 / args.w16a16_steps)
@@ -512,6 +574,8 @@ def main():
                             "unit": "TFLOP/s", "frac": ach16 / PEAK_F16_MFMA_TFLOPS, "traffic": None,
                             "peak_note": PRECISIONS["w16a16"]["note"], "algorithmic_flops_per_launch": flops16,
                             "avg_launch_ms": d16, "launches_per_step": lg.launches[lg.dom]},
+               "timed_regions_ms_per_step": [round(v, 5) for v in m16["regions_ms"]],
+               "dominant_kernel_ms_per_region": [round(v, 5) for v in m16["dom_ms"]],
                "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw16.items()},
                "kernel_ms_per_step": {n: round(v, 4) for n, v in per16.items()}}
         model._engine = eng
@@ -557,9 +621,11 @@ def main():
                        "directed_edges_at_start_and_end_of_timed_region": [2 * pairs_start, 2 * n_pairs],
                        "reset_every": args.reset_every,
                        "untimed": {"warmup_steps": args.warmup, "kernel_profile_steps": N_PROFILE,
-                                   "clock_settle_force_evaluations": n_settle,
-                                   "note": "all before the first barrier of the timed region; the settle phase evaluates "
-                                           "forces at fixed positions (no integration); --settle-seconds 0 disables it"},
+                                   "clock_settle_timesteps": n_settle,
+                                   "note": "all before the first barrier of the timed region; the settle phase is the "
+                                           "timed loop itself (state put back every 40 steps and at its end), enqueued "
+                                           "without a wait, so that only the barrier + synchronize bracket lies between "
+                                           "it and the first timed step; --settle-seconds 0 disables it"},
                        "baseline_note": "2861 = reference README (W16A16, real 1ENH, RTX PRO 6000)"},
             "roofline": {"bound": "mfma", "kernel": leg.dom, "achieved": achieved, "peak": prec["peak"],
                          "unit": "TFLOP/s", "frac": achieved / prec["peak"],
@@ -569,6 +635,8 @@ def main():
                          "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": dom_ms,
                          "launches_per_step": leg.launches[leg.dom]},
             "timed_regions_ms_per_step": [round(v, 5) for v in regions_ms],
+            "dominant_kernel_ms_per_region": [round(v, 5) for v in dom_regions],
+            "smi": meas["smi"],
             "timed_regions_note": (f"{len(regions_ms)} back-to-back repeats of the timed region ({args.steps} steps each, "
                                    "each between its own barrier + synchronize brackets, nothing else in between); the "
                                    "first is `value`; directed_edges_at_start_and_end span all of them"),

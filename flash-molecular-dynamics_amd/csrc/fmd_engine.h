@@ -65,6 +65,7 @@ constexpr int SLICE = 2 * Q1_FLOATS;        // floats of one packed 128x128 node
 // ITEM_INTS ints {molecule (-1: none), first tile, end tile, tile stride, row of the slab buffer that takes the item's
 // aggregate, 0, 0, 0}; workgroup (molecule m, split s) reads items[(m * n_split + s) * 2 + 0 / 1].
 constexpr int ITEM_INTS = 8;
+constexpr int WST_TILE_FLOATS = 32 * F;     // one tile of the filter stash (EdgeArgs::wst): 32 entries x 128 features
 
 struct EdgeArgs {
   const int* items;        // [n_mol * n_split][2][ITEM_INTS]
@@ -91,6 +92,11 @@ struct EdgeArgs {
   float gamma, rc;
   int cap, n_split;
   int max_beads;           // the caller's bound on beads per molecule: what the dynamic LDS was sized for
+  // Filter stash of this block, or null: W = filt(d) C(d) of every pair and feature as the forward kernel's consumers
+  // hold it (lane = feature, registers = the tile's entries), written by edge_fwd and read back by edge_bwd, which then
+  // does not recompute layer 1.  Tile t of molecule m: WST_TILE_FLOATS floats at (m * cap / 32 + t) * WST_TILE_FLOATS,
+  // record [feature slice 0..3][register group q 0..3][lane 0..63] x 16 bytes = registers 4q .. 4q+3 of that lane.
+  float* wst;
 #ifdef FMD_PHASE_STAMPS
   unsigned long long* stamps;  // diagnostic build (make stamps) only: [workgroup][8 waves][FMD_NSTAMP] cycle totals
   int dbg;                     // diagnostic build only: bit 0 = consumers skip their A-B work, bit 1 = producers skip staging
@@ -192,7 +198,7 @@ int setup_edge_bwd_attrs();
 int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s);
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s);
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s);
-int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol, hipStream_t s);
+int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol, hipStream_t s);  // a.wst != null with need_gx1: the stash form
 int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x1, float* x, float* x1,
                       int64_t n_nodes, const SchedArgs& sa, hipStream_t s);
 int launch_node_fwd(const NodeFwdArgs& a, unsigned grid, hipStream_t s);

@@ -47,7 +47,11 @@ __device__ __forceinline__ f16x8 gw_frag(gw_lds_ptr a1, gw_lds_ptr a2) {
 
 // FS: feature-split mode for molecules of 284..566 beads, see edge_fwd_split_kernel (each of the molecule's two
 // workgroups: all tiles, 64 features of gx1, its own dE/dd slab -- the u GEMM only sees its 64 features of gW).
-template <int NS0, bool NEED_GX1, bool FIRST, bool SHARE, bool HALF, bool FS>
+// STASH (blocks with a gx1 aggregate): the filter values W = filt C come from the stash the forward kernel of this block
+// wrote (EdgeArgs::wst), so the consumers run no layer 1, the producers hand over no hidden tile, and the tile region
+// only carries the gW image: two barriers per tile (C: gW(t) visible; A: gW(t) consumed, partial sums visible) in the
+// fp32-grade kernel as well.
+template <int NS0, bool NEED_GX1, bool FIRST, bool SHARE, bool HALF, bool FS, bool STASH>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -71,7 +75,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   // barriers go: "hidden consumed" before the gW store (B) and "gW consumed" before the next hidden tile is put (D) only
   // existed because the stores overwrote what the other role was reading.  A: hidden(t) visible, gW(t-S) consumed,
   // partial sums visible.  C: gW(t) visible, hidden(t) consumed.
-  constexpr bool TWOB = HALF && NEED_GX1 && SHARE && !FS;
+  constexpr bool STASHED = NEED_GX1 && STASH;   // no hidden tile, no layer 1
+  constexpr bool TWOB = HALF && NEED_GX1 && SHARE && !FS && !STASHED;
+  constexpr bool TWO = TWOB || STASHED;         // the two-barrier protocol (A, C)
   char* const gw_base = reinterpret_cast<char*>(smem) + (TWOB ? 32 * LDH * 2 : 0);
   float* frag_l2 = gx1;                                          // PIPE: second fragment buffer
   float* gw_img2f = frag_l2 + a.nb * 256;                        // PIPE: second gW image (2 planes, 16 KB)
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             const f32x2 hv = tanh_from_scaled2(splat2(C2) * g0 + f32x2{b4[2 * ep], b4[2 * ep + 1]});
             // the tile carries C h: L1 then yields W = filt C
             const f32x2 ch = splat2(C) * hv;
-            if constexpr (!NEED_GX1) { th[ep] = 0; tl[ep] = 0; }  // no L1 in block 0: no hidden tile
+            if constexpr (!NEED_GX1 || STASHED) { th[ep] = 0; tl[ep] = 0; }  // no L1 (block 0, stash form): no hidden tile
             else if (HALF) { th[ep] = half_pair(ch); tl[ep] = 0; }
             else split_pair_u(ch, th[ep], tl[ep]);
             // k = d(C h)/dd = C (1 - h^2) z' + C' h = (C - (C h) h) z' + C' h
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(nx.k[r]));
       };
       auto put = [&]() {
-        if constexpr (NEED_GX1) {
+        if constexpr (NEED_GX1 && !STASHED) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             *reinterpret_cast<f16x4*>(hid_hi + c32 * LDH + 32 * w + 8 * q + 4 * h) = hh[q];
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       auto tile = [&](int t, KSet& cu, KSet& nx) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S, nx);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
-        if (!TWOB) __syncthreads();     // B(t)
+        if (!TWO) __syncthreads();     // B(t)
         FMD_MARK(1)
         __syncthreads();     // C(t): gW(t) visible (TWOB: and hidden(t) consumed)
         FMD_MARK(2)
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         const float tot = u_gemm_reduce(gw_a1, gw_a2, cu);
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_MARK(3)
-        if (!TWOB) {
+        if (!TWO) {
           __syncthreads();     // D(t): gW consumed, partial sums visible
           FMD_MARK(4)
           if (w == 0 && h == 0) {
@@ -338,9 +344,9 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           put();               // hidden tiles of t+S
         }
         FMD_MARK(5)
-        __syncthreads();     // A(t+S) (TWOB: also gW(t) consumed, partial sums visible)
+        __syncthreads();     // A(t+S) (two-barrier forms: also gW(t) consumed, partial sums visible)
         FMD_MARK(6)
-        if (TWOB && w == 0 && h == 0) {   // (red is next written after C(t+S), which this wave reaches after the read)
+        if (TWO && w == 0 && h == 0) {   // (red is next written after C(t+S), which this wave reaches after the read)
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
           pgd[t * 32 + c32] = FIRST ? sum : cu.gd + sum;
         }
@@ -356,11 +362,26 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       const bool slice_owner = !FS || w < 2;  // FS: waves 2, 3 only share Gaussians and keep the barriers
       const int cw = FS ? 2 * split + (w & 1) : w;
       f16x8 b1h[8], b1l[8];
+      if constexpr (NEED_GX1 && !STASHED) {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
-        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
+        for (int s = 0; s < 8; ++s) {
+          b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
+          if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
+        }
       }
+      // STASHED: this lane's filter values of a tile, as the forward kernel's consumers stored them
+      const float* const wst_m = STASHED ? a.wst + (int64_t)m * a.cap * F + cw * 1024 + lane * 4 : nullptr;
+      f32x16 fl_next = zero16();
+      auto fetch_w = [&](int t) {
+        if constexpr (STASHED) {
+          const float* wt = wst_m + (int64_t)min(t, ntiles - 1) * WST_TILE_FLOATS;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wt + q * 256));
+            fl_next[4 * q] = v[0]; fl_next[4 * q + 1] = v[1]; fl_next[4 * q + 2] = v[2]; fl_next[4 * q + 3] = v[3];
+          }
+        }
+      };
       const int col = 32 * cw + c32;
       // whole-aggregate mode: the row offsets carry the LDS address of the gx1 aggregate (see the forward kernel)
       typedef __attribute__((address_space(3))) float* lds_fp;
@@ -514,15 +535,16 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         share_fragments();
       }
       form_gw();  // first tile
+      if (slice_owner) fetch_w(T0);
       __syncthreads();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < t_end; t += S) {
         fetch_d(t + 2 * S);  // for the fragments written after C(t)
         if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
-          __syncthreads();  // B(t)
+          if (!TWO) __syncthreads();  // B(t)
           __syncthreads();  // C(t)
           if (SHARE) share_fragments();
-          __syncthreads();  // D(t)
+          if (!TWO) __syncthreads();  // D(t)
           __syncthreads();  // A(t+S)
           continue;
         }
@@ -531,19 +553,26 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         FMD_MARK(0)
         // L1 recomputed: filt slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
-        if constexpr (NEED_GX1) {  // (block 0 has no gx1: the filter values and the hidden tile are not needed at all)
+        if constexpr (STASHED) {  // ... or read back from the forward kernel's stash, one tile ahead
+          acc1 = fl_next;
+        } else if constexpr (NEED_GX1) {  // (block 0 has no gx1: the filter values and the hidden tile are not needed at all)
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
           const _Float16* ph = hid_hi + c32 * LDH + 8 * h;
           const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
-          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          // (W16A16: no low plane -- in the side-by-side form hid_lo is the gW image, which other waves write)
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), ah1 = *reinterpret_cast<const f16x8*>(ph + 16);
+          f16x8 al0 = ah0, al1 = ah1;
+          if constexpr (!HALF) {
+            al0 = *reinterpret_cast<const f16x8*>(pl);
+            al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          }
           static_for<0, 8>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             f16x8 ahn = ah1, aln = al1;
             if constexpr (s + 2 < 8) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
-              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+              if constexpr (!HALF) aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
             FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
@@ -606,9 +635,13 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         });
         FMD_MARK(5)
         fetch_meta(t + 2 * S);
+        // The next tile's filter values are requested LAST: the memory counter retires in order, so everything issued
+        // behind a stash load waits for its HBM round trip too -- here the next wait for a younger load is a whole
+        // tile away (the row gathers above are consumed after barrier C, ~0.6 us from now).
+        fetch_w(t + S);
         FMD_MARK(6)
         }
-        if (!TWOB) __syncthreads();  // B(t): hidden tiles consumed
+        if (!TWO) __syncthreads();  // B(t): hidden tiles consumed
         FMD_MARK(2)
         gw_store(gw_base);
         FMD_MARK(3)
@@ -619,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (SHARE) share_fragments();
         form_gw();  // tile t+S
         FMD_MARK(7)
-        if (!TWOB) __syncthreads();  // D(t)
+        if (!TWO) __syncthreads();  // D(t)
         FMD_MARK(8)
         __syncthreads();  // A(t+S)
         FMD_MARK(9)
@@ -650,24 +683,27 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 
 namespace fmd_eng {
 
+// (NEED_GX1, FIRST, SHARE, HALF, FS, STASH); the stash form only exists with a gx1 aggregate
+#define FMD_BWD_5(M_, ST_)                                                                      \
+  M_(true, true, false, false, false, ST_) M_(true, false, false, false, false, ST_)           \
+  M_(true, true, false, true, false, ST_) M_(true, false, false, true, false, ST_)             \
+  M_(true, true, true, false, false, ST_) M_(true, false, true, false, false, ST_)             \
+  M_(true, true, true, true, false, ST_) M_(true, false, true, true, false, ST_)               \
+  M_(true, true, true, false, true, ST_) M_(true, false, true, false, true, ST_)               \
+  M_(true, true, true, true, true, ST_) M_(true, false, true, true, true, ST_)
 #define FMD_BWD_ALL(M_)                                                                         \
-  M_(true, true, false, false, false) M_(true, false, false, false, false)                     \
-  M_(false, true, false, false, false) M_(false, false, false, false, false)                   \
-  M_(true, true, false, true, false) M_(true, false, false, true, false)                       \
-  M_(false, true, false, true, false) M_(false, false, false, true, false)                     \
-  M_(true, true, true, false, false) M_(true, false, true, false, false)                       \
-  M_(false, true, true, false, false) M_(false, false, true, false, false)                     \
-  M_(true, true, true, true, false) M_(true, false, true, true, false)                         \
-  M_(false, true, true, true, false) M_(false, false, true, true, false)                       \
-  M_(true, true, true, false, true) M_(true, false, true, false, true)                         \
-  M_(false, true, true, false, true) M_(false, false, true, false, true)                       \
-  M_(true, true, true, true, true) M_(true, false, true, true, true)                           \
-  M_(false, true, true, true, true) M_(false, false, true, true, true)
+  FMD_BWD_5(M_, false) FMD_BWD_5(M_, true)                                                      \
+  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
+  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
+  M_(false, true, true, false, false, false) M_(false, false, true, false, false, false)       \
+  M_(false, true, true, true, false, false) M_(false, false, true, true, false, false)         \
+  M_(false, true, true, false, true, false) M_(false, false, true, false, true, false)         \
+  M_(false, true, true, true, true, false) M_(false, false, true, true, true, false)
 
 template <int NS0>
 static int set_attrs() {
-#define FMD_ONE(N_, F_, S_, H_, FS_)                                                                          \
-  if (hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_>,                       \
+#define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                     \
+  if (hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_>,                  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)      \
     return FMD_ELAUNCH;
   FMD_BWD_ALL(FMD_ONE)
@@ -690,11 +726,12 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
                              : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag +
                                    (a.fs ? 0 : frag + (size_t)(4096 + 128) * sizeof(float));
   const bool share = lds_sh <= MAX_LDS_BYTES;
+  const bool stash = need && a.wst != nullptr;
   if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
-#define FMD_ONE(N_, F_, S_, H_, FS_)                                                       \
-  if (need == N_ && first == F_ && (share || a.fs) == S_ && half == H_ && a.fs == FS_) {   \
-    edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a); \
-    return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                         \
+#define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                  \
+  if (need == N_ && first == F_ && (share || a.fs) == S_ && half == H_ && a.fs == FS_ && stash == ST_) {  \
+    edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a);      \
+    return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                         \
   }
   FMD_BWD_ALL(FMD_ONE)
 #undef FMD_ONE

@@ -31,7 +31,9 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 // consumer waves (the other two only keep the barriers).  The slab a workgroup writes holds its half and zeros.
 // SH: the tile's Gaussians are computed once per workgroup (producer w: k-step w, while it would wait for barrier B),
 // and reach all producers as split fragments in LDS (see the backward kernel); used when the region fits.
-template <int NS0, bool HALF, bool FS, bool SH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
+// STASH: the consumers also store the filter values W = filt C of every tile (a.wst, see EdgeArgs) for the backward
+// kernel of the same block, which then neither recomputes layer 1 nor needs the hidden tile.
+template <int NS0, bool HALF, bool FS, bool SH, bool STASH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
@@ -46,6 +48,12 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
+  // The barriers of the tile loop order LDS traffic only.  __syncthreads() also releases GLOBAL stores, i.e. waits for
+  // vmcnt(0): with the stash stores in flight that is an HBM write round trip per tile (measured: +46 us per launch).
+  auto tile_barrier = [&]() {
+    if constexpr (STASH) lds_barrier();
+    else __syncthreads();
+  };
   int m_own, split;
   wg_to_mol_split(m_own, split);
   // this workgroup's work items (sched_body): runs of tiles of one molecule, each with its own aggregate and slab
@@ -188,16 +196,16 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       if (SH) {
         gauss();          // first tile (d_n as fetched above)
         put_frags();
-        __syncthreads();  // its fragments visible
+        tile_barrier();  // its fragments visible
       }
       compute(T0 + S);
       if (SH) {
         gauss();          // second tile
-        __syncthreads();  // the first tile's fragments consumed
+        tile_barrier();  // the first tile's fragments consumed
         put_frags();
       }
       put();
-      __syncthreads();  // A(first)
+      tile_barrier();  // A(first)
       FMD_MARK(11)
       if constexpr (DB) {
         int par = 1;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           FMD_MARK(0)
           put_to(par ? hid_lo : hid_hi);  // ... into the plane they are not reading
           FMD_MARK(2)
-          __syncthreads();     // tile t+S visible, tile t consumed
+          tile_barrier();     // tile t+S visible, tile t consumed
           FMD_MARK(3)
         }
       } else {
@@ -214,22 +222,22 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S);  // tile t+S, while the consumers work on tile t
         if (SH) gauss();     // tile t+2S
         FMD_MARK(0)
-        __syncthreads();     // B(t)
+        tile_barrier();     // B(t)
         FMD_MARK(1)
         put();
         if (SH) put_frags();
         FMD_MARK(2)
-        __syncthreads();     // A(t+S)
+        tile_barrier();     // A(t+S)
         FMD_MARK(3)
       }
       }
     } else {
       // ------------------------------------------------------------------ consumer waves
       if (FS && w >= 2) {  // no feature slice for this wave in FS mode: keep the barrier protocol
-        __syncthreads();  // A(first)
+        tile_barrier();  // A(first)
         for (int t = T0; t < t_end; t += S) {
-          __syncthreads();  // B(t)
-          __syncthreads();  // A(t+S)
+          tile_barrier();  // B(t)
+          tile_barrier();  // A(t+S)
         }
       } else {
       const int cw = FS ? 2 * split + w : w;  // feature slice of this wave
@@ -258,6 +266,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         if (FS) *reinterpret_cast<float*>(aggb + (uint32_t)((int)(o >> 1) + lds_adj)) = v;
         else *(lds_fp)(uintptr_t)o = v;
       };
+      float* const wst_m = STASH ? a.wst + (int64_t)m * a.cap * F : nullptr;  // this molecule's tiles of the stash
+      (void)wst_m;
       SegRegs X;
       uint32_t oj_m[16], oi_m[4];
       auto fetch_meta = [&](int t) {
@@ -312,13 +322,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
       // between the two barriers where the producers only write LDS.
       if (SH) {  // the producers' fragment hand-over (see there): two more barriers before the first tile
-        __syncthreads();
-        __syncthreads();
+        tile_barrier();
+        tile_barrier();
       }
       fetch_meta(T0);
       fill();            // X <- first tile (valid rows for the first, zero-weight, update)
       f32x16 fl_prev = zero16();
-      __syncthreads();  // A(first)
+      tile_barrier();  // A(first)
       FMD_MARK(11)
       int par = 0;   // DB: plane that holds tile t
       for (int t = T0; t < t_end; t += S, par ^= 1) {
@@ -378,16 +388,21 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         {
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
+          // (W16A16: no low plane -- in the double-buffered form hid_lo is the OTHER tile, which the producers are writing)
           const _Float16* ph = (DB && par ? hid_lo : hid_hi) + c32 * LDH + 8 * h;
           const _Float16* pl = hid_lo + c32 * LDH + 8 * h;
-          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), al0 = *reinterpret_cast<const f16x8*>(pl);
-          f16x8 ah1 = *reinterpret_cast<const f16x8*>(ph + 16), al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          f16x8 ah0 = *reinterpret_cast<const f16x8*>(ph), ah1 = *reinterpret_cast<const f16x8*>(ph + 16);
+          f16x8 al0 = ah0, al1 = ah1;
+          if constexpr (!HALF) {
+            al0 = *reinterpret_cast<const f16x8*>(pl);
+            al1 = *reinterpret_cast<const f16x8*>(pl + 16);
+          }
           static_for<0, 8>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             f16x8 ahn = ah1, aln = al1;
             if constexpr (s + 2 < 8) {
               ahn = *reinterpret_cast<const f16x8*>(ph + 16 * (s + 2));
-              aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
+              if constexpr (!HALF) aln = *reinterpret_cast<const f16x8*>(pl + 16 * (s + 2));
             }
             FMD_MERGED(HALF, ah0, al0, b1h[s], b1l[s], acc1, drop_l1);
             ah0 = ah1; al0 = al1; ah1 = ahn; al1 = aln;
@@ -398,13 +413,27 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) fl_prev[r] = acc1[r];
         asm volatile("" : "+v"(fl_prev));  // L1 (and its LDS reads) complete before the barrier
+        // STASH: registers 4q .. 4q+3 (entries 8q + 4h .. + 3 of this lane's feature) go out as one 16-byte store each.
+        // They are issued BEHIND the next tile's list loads (below): the memory counter retires in order, so a wait for
+        // loads issued after the stores would also wait for an HBM write round trip.
+        auto stash_tile = [&]() {
+          if constexpr (STASH) {
+            float* wt = wst_m + (int64_t)t * WST_TILE_FLOATS + cw * 1024 + lane * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)  // (streamed: read once, 0.7 ms later, by the backward kernel -- not worth a cache line)
+              __builtin_nontemporal_store(f32x4{fl_prev[4 * q], fl_prev[4 * q + 1], fl_prev[4 * q + 2], fl_prev[4 * q + 3]},
+                                          reinterpret_cast<f32x4*>(wt + q * 256));
+          }
+        };
+        if (DB) stash_tile();
         FMD_MARK(2)
-        __syncthreads();  // B(t): hidden tiles consumed (DB: and tile t+S visible)
+        tile_barrier();  // B(t): hidden tiles consumed (DB: and tile t+S visible)
         FMD_MARK(3)
         if (!DB) {
           fetch_meta(t + S);  // (in the window where the producers write the next tile: the consumers have nothing else there)
+          stash_tile();
           FMD_MARK(4)
-          __syncthreads();  // A(t+S)
+          tile_barrier();  // A(t+S)
           FMD_MARK(5)
         }
       }
@@ -432,20 +461,28 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 
 namespace fmd_eng {
 
-int setup_edge_fwd_attrs() {
-  const void* fns[] = {(const void*)edge_fwd_split_kernel<2, false, false, false>, (const void*)edge_fwd_split_kernel<2, true, false, false>,
-                       (const void*)edge_fwd_split_kernel<2, false, true, false>,  (const void*)edge_fwd_split_kernel<2, true, true, false>,
-                       (const void*)edge_fwd_split_kernel<2, false, false, true>,
-                       (const void*)edge_fwd_split_kernel<4, false, false, false>, (const void*)edge_fwd_split_kernel<4, true, false, false>,
-                       (const void*)edge_fwd_split_kernel<4, false, true, false>,  (const void*)edge_fwd_split_kernel<4, true, true, false>,
-                       (const void*)edge_fwd_split_kernel<4, false, false, true>};
-  for (const void* f : fns)
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)
-      return FMD_ELAUNCH;
+#define FMD_FWD_ALL(M_)                                                                            \
+  M_(false, false, false) M_(true, false, false) M_(false, true, false) M_(true, true, false) M_(false, false, true)
+
+template <int NS0, bool STASH>
+static int set_fwd_attrs() {
+#define FMD_ONE(H_, FS_, SH_)                                                                                  \
+  if (hipFuncSetAttribute((const void*)edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH>,                        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)       \
+    return FMD_ELAUNCH;
+  FMD_FWD_ALL(FMD_ONE)
+#undef FMD_ONE
   return FMD_OK;
 }
+int setup_edge_fwd_attrs() {
+  int rc = set_fwd_attrs<2, false>();
+  if (rc == FMD_OK) rc = set_fwd_attrs<2, true>();
+  if (rc == FMD_OK) rc = set_fwd_attrs<4, false>();
+  if (rc == FMD_OK) rc = set_fwd_attrs<4, true>();
+  return rc;
+}
 
-template <int NS0>
+template <int NS0, bool STASH>
 static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   // [tile region][red 128][centres 64][bias 128][aggregate rows] (the backward kernel's carve: one size for both)
   const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
@@ -455,17 +492,20 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   const size_t lds_sh = (size_t)(TILE_FLOATS + 128 + a.nb * 256 + a.max_beads * F) * sizeof(float);
   const bool sh = !a.fs && !half && lds_sh <= MAX_LDS_BYTES;
   if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
-  if (a.fs && half) edge_fwd_split_kernel<NS0, true, true, false><<<grid, 512, lds, s>>>(a);
-  else if (a.fs) edge_fwd_split_kernel<NS0, false, true, false><<<grid, 512, lds, s>>>(a);
-  else if (sh) edge_fwd_split_kernel<NS0, false, false, true><<<grid, 512, lds_sh, s>>>(a);
-  else if (half) edge_fwd_split_kernel<NS0, true, false, false><<<grid, 512, lds, s>>>(a);
-  else edge_fwd_split_kernel<NS0, false, false, false><<<grid, 512, lds, s>>>(a);
-  return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
+#define FMD_ONE(H_, FS_, SH_)                                                                     \
+  if (half == H_ && a.fs == FS_ && sh == SH_) {                                                   \
+    edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH><<<grid, 512, (SH_) ? lds_sh : lds, s>>>(a);  \
+    return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                \
+  }
+  FMD_FWD_ALL(FMD_ONE)
+#undef FMD_ONE
+  return FMD_EUNSUPPORTED;
 }
 
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
-  return num_rbf <= 32 ? launch_fwd<2>(a, half, grid, s) : launch_fwd<4>(a, half, grid, s);
+  if (a.wst) return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s) : launch_fwd<4, true>(a, half, grid, s);
+  return num_rbf <= 32 ? launch_fwd<2, false>(a, half, grid, s) : launch_fwd<4, false>(a, half, grid, s);
 }
 
 }  // namespace fmd_eng

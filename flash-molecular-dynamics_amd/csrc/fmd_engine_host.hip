@@ -94,6 +94,7 @@ struct Workspace {
   float* x1[8];
   float* t[8];
   float* slabs;
+  float* wst[8];    // filter stash of block l (null: block 0, or stash disabled)
   uint32_t *poi, *poj;
   int32_t* npairs;
   int32_t* report;  // [n_mol][3] pairs_kernel -> finish_kernel
@@ -172,6 +173,13 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   w.report = (int32_t*)take(n_mol * 12);
   w.items = (int*)take(n_mol * n_split * 2 * ITEM_INTS * 4);
   w.extra_row = (int*)take(n_nodes * 4);
+  // filter stash (EdgeArgs::wst): one float per list entry and feature, for every block whose backward pass has a gx1
+  // aggregate to update (all but the first).  Last in the carve: nothing else moves when it is switched off.
+  // fp32-grade precision only: with a third of the MFMA work the W16A16 kernels gain less from the dropped layer than the
+  // stash traffic costs them (same-box A/B: 108.2k against 110.5k timestep*mol/s).
+  const bool stash = d->precision == FMD_PREC_F32 && !(d->flags & FMD_FLAG_NO_FILTER_STASH);
+  for (int l = 0; l < d->num_blocks; ++l)
+    w.wst[l] = (l > 0 && stash) ? (float*)take(n_mol * cap * F * (int64_t)sizeof(float)) : nullptr;
   w.total = p - reinterpret_cast<char*>(base);
   return w;
 }
@@ -186,6 +194,7 @@ bool desc_ok(const fmd_schnet_desc* d) {
   if (d->out_width[d->num_out - 1] != 1) return false;
   if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_W16A16) return false;
   if (d->embedding_size < 1) return false;
+  if (d->flags & ~FMD_FLAG_NO_FILTER_STASH) return false;
   return true;
 }
 
@@ -376,6 +385,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.centers = pk + PL.centers; ea.slabs = ws.slabs; ea.slab_stride = slab_stride;
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
+    ea.wst = ws.wst[l];
 #ifdef FMD_PHASE_STAMPS
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
     ea.dbg = (ea.stamps || g_stamp_block == -2) ? g_stamp_dbg : 0;   // block -2: the switches apply to every launch

@@ -554,14 +554,18 @@ __global__ __launch_bounds__(256) void node_embed_kernel(const int64_t* __restri
 // (tools/ubench/lds_atomic_int.hip), integer addition commutes -- any order of the atomics gives the same bits.
 // The conversion is sign-symmetric, fixed(-x) = -fixed(x): |x| is cut into its integer part and a 32-bit fraction
 // (both exact in fp32: x * 2^32 only moves the exponent), every addend is therefore exact whenever |x| >= 2^-32 * 2^23
-// and truncated towards zero by less than 2^-32 otherwise.  A value that does not fit (|x| >= 2^31, Inf, NaN) cannot
-// be carried by an integer: it raises `bad`, and the caller of this helper then poisons the molecule's forces with NaN
-// and sets the sticky status word, so a blow-up stays as visible as it was with float atomics.  The four copies are
-// added as integers, converted once; the two workgroups then add their halves to the force array that pairs_kernel
-// zeroed: two addends commute.
+// and truncated towards zero by less than 2^-32 otherwise.  The 64-bit sum carries |integer part| < 2^31 and collects
+// at most 2 (n - 1) addends per bead and wave copy, four copies, n <= 535: fewer than 2^12 addends in all.  An addend
+// is therefore accepted only below FMD_FIXED_LIMIT = 2^19 (2^12 x 2^19 = 2^31: the sum cannot wrap); anything larger,
+// Inf or NaN raises `bad`, and the caller of this helper then poisons the molecule's forces with NaN and sets the
+// sticky status word, so a blow-up stays as visible as it was with float atomics and never turns into a finite wrong
+// force (a per-pair force of 5e5 in the model's units is a diverged system by any measure).  The four copies are added as
+// integers, converted once; the two workgroups then add their halves to the force array that pairs_kernel zeroed: two
+// addends commute.
+constexpr float FMD_FIXED_LIMIT = 524288.0f;  // 2^19
 __device__ __forceinline__ unsigned long long fmd_to_fixed(float x, bool& bad) {
   const float ax = fabsf(x);
-  bad = bad || !(ax < 2147483648.0f);          // also true for NaN
+  bad = bad || !(ax < FMD_FIXED_LIMIT);        // also true for NaN
   const float ip = truncf(ax);
   const float fr = (ax - ip) * 4294967296.0f;  // exact, in [0, 2^32)
   const unsigned long long q = ((unsigned long long)(unsigned)ip << 32) | (unsigned long long)(unsigned)fr;
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   unsigned long long* g = gall + wv * 3 * n;  // this wave's [3n] dE/dpos, fixed point
   __shared__ float esum[4];
   __shared__ int bad_s;
-  bool bad = false;  // a contribution that the fixed-point sum cannot carry (Inf, NaN, |x| >= 2^31)
+  bool bad = false;  // a contribution that the fixed-point sum cannot carry (Inf, NaN, |x| >= FMD_FIXED_LIMIT)
   if (tid == 0) bad_s = 0;
   for (int i = tid; i < 12 * n; i += 256) gall[i] = 0ull;
   __syncthreads();

@@ -58,7 +58,12 @@ class SchnetDesc(ctypes.Structure):
     _fields_ = [("hidden", ctypes.c_int32), ("num_rbf", ctypes.c_int32), ("num_blocks", ctypes.c_int32),
                 ("num_out", ctypes.c_int32), ("out_width", ctypes.c_int32 * 4),
                 ("embedding_size", ctypes.c_int32), ("precision", ctypes.c_int32),
-                ("n_split", ctypes.c_int32), ("cutoff", ctypes.c_float), ("gamma", ctypes.c_float)]
+                ("n_split", ctypes.c_int32), ("cutoff", ctypes.c_float), ("gamma", ctypes.c_float),
+                ("flags", ctypes.c_int32)]
+
+
+FLAG_NO_FILTER_STASH = 1   # FMD_FLAG_NO_FILTER_STASH
+ABI_VERSION = 4            # what this binding (and engine.py's handling of the status words) was written for
 
 
 class SchnetBlockWeights(ctypes.Structure):
@@ -89,6 +94,12 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
+        got = handle.fmd_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(
+                f"flashmd_amd: {LIB_PATH} implements ABI {got}, this package expects ABI {ABI_VERSION} (same signatures, "
+                "different status-word and workspace rules): rebuild it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = handle
     return _lib
 

@@ -81,9 +81,11 @@ def _output_weights(on):
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None):
+    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True):
         """``precision``: "f32" (default) or "w16a16"; a model whose filter and output networks
-        were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself."""
+        were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself.  ``filter_stash=False``: the
+        backward pair kernels recompute filter layer 1 instead of reading the values the forward kernels kept
+        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits)."""
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -135,6 +137,7 @@ class FusedSchNetEngine:
             raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
         d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
+        d.flags = 0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH
         self.desc = d
 
         # host copies of the weights (fp32, contiguous) -> packed register-order buffer -> device

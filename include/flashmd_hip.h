@@ -191,7 +191,14 @@ typedef struct fmd_schnet_desc {
                             > 0 = fixed static interleave */
   float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
   float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
+  int32_t flags;         /* 0, or FMD_FLAG_NO_FILTER_STASH (ABI 4) */
 } fmd_schnet_desc;
+/* By default (FMD_PREC_F32 only) the forward pair kernel of every block but the first keeps its filter values W = filt(d) C(d) (fp32, one per
+ * list entry and feature: n_mol * max_pairs_per_mol * 512 bytes of workspace per such block, of which the entries a
+ * batch really has are touched) and the backward kernel of that block reads them back instead of recomputing filter
+ * layer 1.  With this flag the workspace stays small and the backward pass recomputes (same results to the last bit:
+ * the recomputation runs the same arithmetic). */
+#define FMD_FLAG_NO_FILTER_STASH 1
 
 /* Host pointers to the reference's parameter tensors (fp32, nn.Linear [out,in] layout). */
 typedef struct fmd_schnet_block_weights {

@@ -835,3 +835,39 @@ def test_engine_from_state_dict_file(params, golden_dir, tmp_path):
     e, f = eng.energy_forces(pos, types, ptr, 269)
     re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
     assert re < 2e-5 and rf < 2e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
+@pytest.mark.parametrize("shape", ["8x269", "ragged", "fs_2x400"])
+def test_filter_stash_matches_recomputation(params, precision, shape):
+    """The default engine keeps the forward kernels' filter values for the backward kernels of blocks 1.. (the stash,
+    EdgeArgs::wst); FMD_FLAG_NO_FILTER_STASH recomputes filter layer 1 there as rounds 1-3 did.  The stash holds exactly
+    what the recomputation produces (same MFMA sequence on the same operands), so energies AND forces must agree to the
+    last bit -- in both precisions, for ragged batches (work items that hand tiles to other workgroups) and in
+    feature-split mode (400 beads: two workgroups per molecule, 64 features each)."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    if shape == "8x269":
+        pos, types, ptr = so.synth_batch(8, 269, 5.0)
+    elif shape == "fs_2x400":
+        pos, types, ptr = so.synth_batch(2, 400, 5.0)
+    else:
+        parts = [so.synth_batch(1, n, 5.0, first_mol=77 + n) for n in (269, 31, 150, 2, 97, 269, 64, 200)]
+        pos = torch.cat([q[0] for q in parts])
+        types = torch.cat([q[1] for q in parts])
+        ptr = torch.tensor([0] + list(np.cumsum([q[0].shape[0] for q in parts])), dtype=torch.int64)
+    model = S.model_from_params(params).to(DEV)
+    stash = engine.FusedSchNetEngine(model, precision=precision)
+    plain = engine.FusedSchNetEngine(model, precision=precision, filter_stash=False)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    mb = int((ptr[1:] - ptr[:-1]).max())
+    e1, f1 = stash.energy_forces(P, T, Q, mb)
+    e2, f2 = plain.energy_forces(P, T, Q, mb)
+    assert torch.isfinite(f1).all()
+    assert torch.equal(e1, e2)
+    d = float((f1 - f2).norm() / f2.norm())
+    print(f"{shape} {precision}: stash vs recomputation, forces differ by {d:.2e}")
+    assert torch.equal(f1, f2)
+    e3, f3 = stash.energy_forces(P, T, Q, mb)   # and a second call reuses the stash buffer
+    assert torch.equal(f1, f3)
