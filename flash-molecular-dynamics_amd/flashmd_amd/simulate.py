@@ -84,12 +84,60 @@ class LangevinSimulation:
         self.noise = torch.empty_like(self.x)
         self.energy, self.f = self.force_fn(self.x)
         self.n_sims = beta_mol.numel()
+        self.t_init = 0           # chunk index a resumed run continues from (load_checkpoint); 0 = a fresh run
+        self._graph = None        # hipGraph of the timestep (capture()), replayed by timestep()
+        self._graph_steps = 1
 
     def draw_noise(self):
         """fills self.noise with N(0,1) (reference langevin.py:146: ``_noise_buffer.normal_(generator=self.rng)``)"""
         self.noise.normal_(generator=self.rng)
 
+    def capture(self, steps_per_graph: int = 1, warmup: int = 2):
+        """Record ``steps_per_graph`` timesteps -- noise draw, first BAOAB half, every launch of the force providers,
+        second half -- as ONE hipGraph; ``timestep()`` then replays it (and advances ``steps_per_graph`` steps per
+        call).  This build's answer to the reference's ``torch.compile`` wrapper around the model
+        (simulation/base.py:357-368): shapes, workspace and weights are static, so the host's per-step work (0.8-1.0 ms
+        of Python and ctypes for ~19 launches) shrinks to one graph launch.  Results are those of the un-captured loop
+        to the last bit (same kernels, same order, same Philox offsets: the generator is registered with the graph).
+        The force providers must already have seen this batch layout (no allocation, status read or other
+        synchronisation may happen while a stream is capturing): ``warmup`` un-captured steps run first, on a copy of the
+        state that is put back.  Device status words are NOT read during replays -- call ``check_status()`` at the
+        run's natural synchronisation points, as ``simulate()`` does; the sticky status word keeps any failure."""
+        if not (self.use_hip and self.x.is_cuda):
+            raise RuntimeError("capture() needs the HIP path on a GPU")
+        assert steps_per_graph >= 1
+        self._graph = None
+        state = (self.x.clone(), self.v.clone(), self.f.clone(), self.energy.clone(), self.rng.get_state())
+        for _ in range(max(1, warmup)):
+            self.timestep()
+        self.check_status()                     # (also resets the providers' "evaluations since the last read" counters)
+        self.x.copy_(state[0]); self.v.copy_(state[1])
+        # forces and energies live in fixed buffers from here on: a replay reads what the previous replay wrote
+        self.f, self.energy = state[2], state[3]
+        self.rng.set_state(state[4])
+        g = torch.cuda.CUDAGraph()
+        g.register_generator_state(self.rng)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(steps_per_graph):
+                self.noise.normal_(generator=self.rng)
+                langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt, self.friction)
+                e, f = self.force_fn(self.x)
+                self.energy.copy_(e)
+                self.f.copy_(f)
+                langevin_post(self.v, self.f, self.masses, self.dt)
+        self._graph, self._graph_steps = g, steps_per_graph
+        return self
+
+    def release_graph(self):
+        """back to the un-captured loop (e.g. before the batch layout or the force providers change)"""
+        self._graph = None
+        self._graph_steps = 1
+
     def timestep(self):
+        if self._graph is not None:   # ``_graph_steps`` timesteps per call
+            self._graph.replay()
+            return
         self.draw_noise()
         if self.use_hip:
             langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt,
@@ -117,8 +165,11 @@ class LangevinSimulation:
         half = n_timesteps // 2
         t0 = None
         sync = torch.cuda.synchronize if self.x.is_cuda else (lambda: None)
-        if writer is not None and writer.index == 0 and writer.count == 0:
+        # the reference writes {filename}_checkpoint_init.pt only when a run starts at t_init == 0
+        # (simulation/base.py:538): a run resumed through load_checkpoint() must not overwrite it with mid-run state
+        if writer is not None and self.t_init == 0 and writer.index == 0 and writer.count == 0:
             writer.write_initial_checkpoint(self)
+        assert self._graph is None or self._graph_steps == 1, "simulate() counts single timesteps: capture(1)"
         for t in range(n_timesteps):
             if t == half:
                 sync()
@@ -156,8 +207,11 @@ class LangevinSimulation:
         ck = torch.load(path, weights_only=True)
         self.x = ck["pos"].to(self.x.device, self.x.dtype).contiguous()
         self.v = ck["velocities"].to(self.v.device, self.v.dtype).contiguous()
+        if self._graph is not None:   # the captured graph works on the old buffers
+            self.release_graph()
         self.energy, self.f = self.force_fn(self.x)
-        return int(ck["current_timestep"])
+        self.t_init = int(ck["current_timestep"])
+        return self.t_init
 
 
 class TrajectoryWriter:
@@ -190,7 +244,8 @@ class TrajectoryWriter:
         self.kinetic = torch.zeros(self.frames, n_sims, device=dev) if save_energies else None
         self.initial_spread = sim.x.view(n_sims, -1).std(dim=1).max()
         self.diverged = torch.zeros((), dtype=torch.bool, device=dev)
-        self.index = 0            # chunk counter (the XXXX of the file names)
+        self.index = int(getattr(sim, "t_init", 0))   # chunk counter (the XXXX of the file names); a resumed run goes on
+                                                       # where its checkpoint stopped (reference simulation/base.py:1100-1102)
         self.count = 0            # frames staged in the current chunk
         self.files = []
         self._stream = torch.cuda.Stream(device=dev) if sim.x.is_cuda else None

@@ -168,6 +168,15 @@ def test_trajectory_writer_layout_and_checkpoint_resume(tmp_path):
     sim2 = simulate.LangevinSimulation(ff, pos, masses, beta, n_atoms, dt=0.004, use_hip=False)
     assert sim2.load_checkpoint(f"{base}_checkpoint_0001.pt") == 2
     assert torch.equal(sim2.x, frames[-1][0]) and torch.equal(sim2.v, frames[-1][4])
+    # a resumed run (t_init != 0) with a FRESH writer must leave {filename}_checkpoint_init.pt alone: the reference
+    # writes it only when t_init == 0 (simulation/base.py:538) -- mid-run state labelled timestep 0 would be a lie
+    init_before = torch.load(f"{base}_checkpoint_init.pt", weights_only=True)
+    assert init_before["current_timestep"] == 0 and torch.equal(init_before["pos"], pos)
+    wr2 = simulate.TrajectoryWriter(base, sim2, save_interval=2, export_interval=10, create_checkpoints=True)
+    sim2.simulate(10, writer=wr2)
+    assert os.path.exists(f"{base}_coords_0002.npy")   # the resumed run continues the chunk numbering
+    init_after = torch.load(f"{base}_checkpoint_init.pt", weights_only=True)
+    assert torch.equal(init_after["pos"], init_before["pos"]) and torch.equal(init_after["velocities"], init_before["velocities"])
 
 
 def test_state_dict_loaders_row_n4(tmp_path, golden_dir):

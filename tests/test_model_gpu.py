@@ -871,3 +871,48 @@ def test_filter_stash_matches_recomputation(params, precision, shape):
     assert torch.equal(f1, f2)
     e3, f3 = stash.energy_forces(P, T, Q, mb)   # and a second call reuses the stash buffer
     assert torch.equal(f1, f3)
+
+
+@pytest.mark.parametrize("precision,steps_per_graph", [("f32", 1), ("f32", 3), ("w16a16", 1)])
+def test_captured_timestep_is_bit_identical(params, precision, steps_per_graph):
+    """LangevinSimulation.capture(): noise draw + BAOAB halves + the engine's 15 launches as ONE hipGraph (this build's
+    counterpart of the reference's torch.compile wrapper, simulation/base.py:357-368).  Twelve replayed timesteps must
+    equal twelve un-captured ones bit for bit -- positions, velocities, forces, energies -- through the
+    reference-shaped entry GradientsOut(model)(batch), and the device status must still be readable afterwards."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, simulate
+
+    S.USE_FUSED_ENGINE = True
+    pos, types, ptr = so.synth_batch(6, 269, 5.0)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    masses = torch.full((P.shape[0],), 12.0, device=DEV)
+    beta = torch.full((6,), 1.67, device=DEV)
+
+    def make():
+        model = S.model_from_params(params).to(DEV)
+        model._engine = engine.FusedSchNetEngine(model, precision=precision)
+        go = S.GradientsOut(model).eval()
+        batch = S.Batch(P.clone(), T, Q, max_beads_per_mol=269)
+
+        def force(x):
+            batch.pos, batch.out = x, {}
+            d = go(batch)
+            return d.out["SchNet"]["energy"], d.out["SchNet"]["forces"]
+
+        return simulate.LangevinSimulation(force, P, masses, beta, 269, dt=0.004, friction=1.0, seed=11)
+
+    eager, graph = make(), make()
+    graph.capture(steps_per_graph=steps_per_graph)
+    assert torch.equal(eager.x, graph.x) and torch.equal(eager.v, graph.v) and torch.equal(eager.f, graph.f)
+    for _ in range(12):
+        eager.timestep()
+    for _ in range(12 // steps_per_graph):
+        graph.timestep()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eager.f).all()
+    assert torch.equal(eager.x, graph.x), float((eager.x - graph.x).abs().max())
+    assert torch.equal(eager.v, graph.v) and torch.equal(eager.f, graph.f) and torch.equal(eager.energy, graph.energy)
+    graph.check_status()
+    graph.release_graph()
+    eager.timestep(); graph.timestep()
+    assert torch.equal(eager.x, graph.x)

@@ -56,6 +56,21 @@ def measure(name, fn, per_step):
     print(f"{name:34s} enqueue {1e3 * t_enq / args.steps:7.3f} ms/step   complete {1e3 * t_all / args.steps:7.3f} ms/step")
 
 
+def measure_graph(name, fn, k):
+    sim = simulate.LangevinSimulation(fn, pos, masses, beta, args.beads).capture(steps_per_graph=k)
+    for _ in range(200 // k):
+        sim.timestep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps // k):
+        sim.timestep()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    n = args.steps // k * k
+    print(f"{name:34s} enqueue {1e3 * t_enq / n:7.3f} ms/step   complete {1e3 * t_all / n:7.3f} ms/step")
+
+
 measure("force only, direct engine", direct, lambda s: s.force_fn(s.x))
 measure("force only, GradientsOut", via_go, lambda s: s.force_fn(s.x))
 measure("BAOAB step, direct engine", direct, lambda s: s.timestep())
@@ -69,3 +84,5 @@ t0 = time.perf_counter()
 for _ in range(2000):
     torch.empty(args.batch * args.beads, 3, dtype=torch.float32, device=dev)
 print(f"torch.empty                         {1e6 * (time.perf_counter() - t0) / 2000:7.2f} us")
+measure_graph("timestep, hipGraph (1 step/graph)", via_go, 1)
+measure_graph("timestep, hipGraph (4 steps/graph)", via_go, 4)
