@@ -529,6 +529,31 @@ def main():
         direct_ms = 1e3 * max_over_ranks(time.perf_counter() - td) / k_dir
         sim.force_fn = leg.force_via_gradients_out
 
+    # the same loop replayed from ONE hipGraph per timestep (LangevinSimulation.capture(): this build's counterpart of
+    # the reference's torch.compile wrapper).  Reported beside the line, never as `value`: the events that time the
+    # dominant kernel are recorded by the un-captured path.
+    graph_info = None
+    if not args.pt and world == 1:
+        st = leg.save_state()
+        sim.capture()
+        k_g = min(max(args.steps, 20), 200)
+        for _ in range(k_g):
+            sim.timestep()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(k_g):
+            sim.timestep()
+        t_enq = time.perf_counter() - tg
+        barrier()
+        t_all = time.perf_counter() - tg
+        sim.check_status()
+        sim.release_graph()
+        graph_info = {"ms_per_step": 1e3 * t_all / k_g, "value": k_g * args.batch / t_all, "steps": k_g,
+                      "host_enqueue_ms_per_step": 1e3 * t_enq / k_g,
+                      "note": "one hipGraph replay per timestep (noise draw, BAOAB halves, every engine launch); "
+                              "bit-identical to the un-captured loop (tests/test_model_gpu.py)"}
+        leg.restore_state(st)
+
     pt_info = None
     if exchange is not None:
         m = exchange.acceptance_matrix() if world > 1 else exchange.acceptance_matrix
@@ -651,6 +676,8 @@ def main():
         }
         if direct_ms is not None:
             line["ms_per_step_direct_engine_call"] = direct_ms
+        if graph_info is not None:
+            line["graph_replay"] = graph_info
         if pt_info is not None:
             line["parallel_tempering"] = pt_info
         if marks:

@@ -247,6 +247,26 @@ def test_bench_launches_its_own_ranks():
     assert line == {"launch_check": True, "n_gpus": 2, "rank_sum": 1, "gpus_arg": 2}
 
 
+@pytest.mark.parametrize("extra", [[], ["--pt"]])
+def test_bench_launch_path_with_eight_ranks(extra):
+    """The driver's exact multi-GPU command lines, `python bench.py --gpus 8 [--pt] --steps 20 --warmup 5`, as far as
+    they go without GPUs: the script starts eight ranks itself (child torch.distributed.run, rendezvous on 127.0.0.1),
+    all eight rendezvous (gloo) and rank 0 reports who was there."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FMD_BENCH_LAUNCH_CHECK="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5",
+                          *extra], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 8, "rank_sum": 28, "gpus_arg": 8}
+
+
 def test_bench_exchange_attempts_fall_inside_a_short_timed_region():
     """--pt must time at least one even- and one odd-phase attempt whatever --steps is (the driver runs 40 steps against
     an exchange interval of 100); long regions keep the reference's schedule (parallel_tempering.py:349-366)."""

@@ -83,12 +83,21 @@ elif mode == "pt":
     sys.stdout.flush()
     # two temperatures: there is no odd pair and the reference proposes (0, 1) again (parallel_tempering.py:262-263)
     assert ex.partner(False) == peer
-elif mode == "pt4":
+elif mode in ("pt4", "pt8"):
     # four temperatures, one per rank: attempt 0 pairs (0,1),(2,3); attempt 1 pairs (1,2) while ranks 0 and 3 sit out
     # (reference parallel_tempering.py:256-284,349-366); attempt 2 is even again.  Every attempt is checked against
     # the expectation computed from the gathered pre-exchange state, and the acceptance matrix against the
     # reference's bookkeeping (:99-104,407-412): accepted above the diagonal, rejected below.
-    betas = [1.67, 1.42, 1.16, 0.95]
+    # pt8: BASELINE configs[4]'s shape -- the ladder of EIGHT temperatures bench.py --pt --gpus 8 uses, one per rank,
+    # four attempts (even, odd, even, odd): (0,1)(2,3)(4,5)(6,7) then (1,2)(3,4)(5,6) with ranks 0 and 7 idle.
+    if mode == "pt8":
+        sys.path.insert(0, %(root)r)
+        import bench
+        betas = bench.beta_ladder(8)
+        assert world == 8 and abs(betas[1] - 1.42) < 0.03 and abs(betas[2] - 1.16) < 1e-6
+    else:
+        betas = [1.67, 1.42, 1.16, 0.95]
+    n_attempts = 4 if mode == "pt8" else 3
     n_indep = 3
     sl = slice(0, n_indep * A)
     ptr_l = torch.arange(n_indep + 1) * A
@@ -103,7 +112,7 @@ elif mode == "pt4":
         counted[0] += 1
         return inner(x)
     sim.force_fn = counting
-    for attempt in range(3):
+    for attempt in range(n_attempts):
         for _ in range(2): sim.timestep()
         x0, v0, u0 = sim.x.clone(), sim.v.clone(), sim.energy.clone()
         allx = [torch.empty_like(x0) for _ in range(world)]; dist.all_gather(allx, x0)
@@ -112,7 +121,8 @@ elif mode == "pt4":
         before = counted[0]
         ex(sim)
         pairs = simulate.pt_pairs(world, attempt %% 2 == 0)
-        assert pairs == ([(0, 1), (2, 3)] if attempt %% 2 == 0 else [(1, 2)])
+        assert pairs == ([(k, k + 1) for k in range(0, world - 1, 2)] if attempt %% 2 == 0 else
+                         [(k, k + 1) for k in range(1, world - 1, 2)])
         x_exp, v_exp, moved = allx[rank], allv[rank], False
         for a, b in pairs:
             g = torch.Generator().manual_seed((5 * 1000003 + attempt) * 4099 + a)
@@ -128,7 +138,9 @@ elif mode == "pt4":
         # forces are re-evaluated only where something was accepted (idle ranks and all-rejected pairs: not)
         ok = ok and (counted[0] - before == (1 if moved else 0))
     m = ex.acceptance_matrix()
-    ok = ok and torch.equal(m, expected) and int(m.sum()) == n_indep * (2 + 1 + 2)
+    n_even, n_odd = (n_attempts + 1) // 2, n_attempts // 2
+    ok = ok and torch.equal(m, expected) and int(m.sum()) == n_indep * (n_even * (world // 2) + n_odd * ((world - 1) // 2))
+    ok = ok and int(torch.triu(m, 2).sum() + torch.tril(m, -2).sum()) == 0   # only ladder neighbours ever exchange
     sys.stdout.write(f"PT4_OK {int(ok)} {rank} {int(m[0, 1] + m[1, 0])} {int(m[1, 2] + m[2, 1])}\n")
     sys.stdout.flush()
 dist.barrier()
@@ -191,3 +203,20 @@ def test_parallel_tempering_exchange_four_ranks_odd_phase_and_matrix():
     for ok, rank, n01, n12 in recs:
         assert int(ok) == 1, f"rank {rank}"
         assert int(n01) == 6 and int(n12) == 3   # (0,1): two even attempts x 3 replicas; (1,2): one odd attempt
+
+
+def test_parallel_tempering_exchange_eight_ranks_the_bench_ladder():
+    """BASELINE configs[4] without the hardware: eight ranks over gloo, the ladder of eight temperatures that
+    `bench.py --pt --gpus 8` builds, both phases twice; every attempt against the expectation from the gathered
+    pre-exchange state, the acceptance matrix against the reference's bookkeeping
+    (simulation/parallel_tempering.py:99-104,407-412), idle end ranks in the odd phase, no force re-evaluation without
+    an accepted pair."""
+    out = _run("pt8", nproc=8)
+    import re
+
+    recs = re.findall(r"PT4_OK (\d+) (\d+) (\d+) (\d+)", out)
+    assert len(recs) == 8, out[-800:]
+    assert sorted(int(r[1]) for r in recs) == list(range(8))
+    for ok, rank, n01, n12 in recs:
+        assert int(ok) == 1, f"rank {rank}"
+        assert int(n01) == 6 and int(n12) == 6   # two even attempts on (0,1), two odd attempts on (1,2), 3 replicas each
