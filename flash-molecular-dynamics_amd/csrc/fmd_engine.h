@@ -11,12 +11,14 @@
 //    producers (rbf, filter layer 0, tanh -> hidden tile in LDS) and consumers (filter layer 1, row
 //    gathers, aggregate update), each owning a 32-feature slice whose weight fragments live in VGPRs.
 //    Every aggregate element is touched by exactly one wave in program order => bit-reproducible sums;
-//  * contractions: precision FMD_PREC_F32 = split-operand f16 MFMA (x = hi + lo/2048, three products,
-//    fp32 accumulation, 2e-7 = the error of the fp32 MFMA at 3/16 of its cycles); FMD_PREC_W16A16 = one
-//    product of fp16-rounded operands;
-//  * backward recomputes the filter instead of storing [E,F] tensors, and gets d/d(distance) from
-//    the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice GEMMs), so the only
-//    per-pair quantity that reaches HBM is one float (dE/dd) per pair.
+//  * contractions: precision FMD_PREC_F32 = split-operand f16 MFMA (x = hi + lo, three products, fp32
+//    accumulation, 2e-7 = the error of the fp32 MFMA at 3/16 of its cycles; bounded operands carry an unscaled low
+//    word and share ONE accumulator, only gW keeps lo = f16((x - hi) * 2048) and a second one, see split_pair_u /
+//    split_pair); FMD_PREC_W16A16 = one product of fp16-rounded operands;
+//  * backward gets d/d(distance) from the forward-mode product z' = W0 rbf'(d) and u = gW W1 (two extra slice
+//    GEMMs), so the only per-pair OUTPUT that reaches HBM is one float (dE/dd) per pair.  The filter values W of
+//    blocks 1.. are kept by the forward kernel (the filter stash, EdgeArgs::wst: one float per pair and feature)
+//    and read back once instead of recomputing layer 1 (FMD_PREC_F32; block 0 and W16A16 recompute / need none).
 #pragma once
 #include <string.h>
 #include <type_traits>

@@ -1,7 +1,8 @@
 // Fused engine, host side: weight packing, workspace carve-up, the launch sequence of one force evaluation and the
 // C-ABI entry points fmd_schnet_* (include/flashmd_hip.h).  Replaces SchNet.forward + GradientsOut.forward of the
-// reference (models/schnet.py:178-369, models/gradients.py:226-290) for StandardSchNet models with
-// hidden = filters = 128.  The kernels live in fmd_engine_{pairs,edge_fwd,edge_bwd,node}.hip.
+// reference (models/schnet.py:178-369, models/gradients.py:226-290) for StandardSchNet models whose weights the caller
+// has zero-padded to the kernels' width, hidden = filters = 128.  The kernels live in
+// fmd_engine_{pairs,edge_fwd,edge_bwd,node}.hip.
 #include <atomic>
 #include <vector>
 

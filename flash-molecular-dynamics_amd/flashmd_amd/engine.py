@@ -1,5 +1,5 @@
-"""Fused whole-path engine: energy[B] and forces[N,3] of a batch in one HIP pipeline with no
-[E,F] tensor in HBM (csrc/fmd_fused.hip behind fmd_schnet_energy_forces).
+"""Fused whole-path engine: energy[B] and forces[N,3] of a batch in one HIP pipeline of 15 launches
+(csrc/fmd_engine_{pairs,edge_fwd,edge_bwd,node,host}.hip behind fmd_schnet_energy_forces).
 
 Replaces, for qualifying models, what the reference does per timestep in SchNet.forward +
 GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model

@@ -133,14 +133,34 @@ class StaticPriors:
 
     @classmethod
     def from_tables(cls, spec: Dict[str, Tuple[Dict[str, torch.Tensor], torch.Tensor]], types, mol_ptr):
-        """spec: kind -> (per-type parameter tables, mapping [order, M]); types [N], mol_ptr [B+1] on the CPU."""
+        """spec: kind -> (per-type parameter tables, mapping [order, M]) -- or a LIST of such pairs: several prior
+        models of one kind (the reference's GeneralBonds / GeneralAngles exist so that a SumOut can hold more than one
+        bond or angle model) are condensed into one term list the way condense_all_priors_for_simulation does it
+        (simulation/specialize_prior.py:159-196): mappings concatenated, per-term parameters looked up model by model
+        and concatenated, Fourier series padded with zero amplitudes to the longest expansion.
+        types [N], mol_ptr [B+1] on the CPU."""
         n_beads = int(mol_ptr[-1])
         terms = {}
-        for kind, (tables, mapping) in spec.items():
-            assert kind in KIND and mapping.shape[0] == ORDER[kind] and mapping.dtype == torch.int64
+        for kind, members in spec.items():
+            if isinstance(members, tuple):
+                members = [members]
+            assert kind in KIND and members
+            looked = []
+            for tables, mp in members:
+                assert mp.shape[0] == ORDER[kind] and mp.dtype == torch.int64
+                looked.append(_lookup(kind, tables, types, mp).to(torch.float32))
+            if kind == "dihedrals" and len(looked) > 1:   # rows: v_0, k1s[0..n), k2s[0..n) -> pad n to the largest
+                n_max = max((q.shape[0] - 1) // 2 for q in looked)
+                padded = []
+                for q in looked:
+                    n = (q.shape[0] - 1) // 2
+                    z = torch.zeros(n_max - n, q.shape[1])
+                    padded.append(torch.cat([q[:1 + n], z, q[1 + n:], z]))
+                looked = padded
+            params = torch.cat(looked, dim=1)
+            mapping = torch.cat([mp for _, mp in members], dim=1)
             order, n_terms = mapping.shape
             assert n_terms < (1 << 29)
-            params = _lookup(kind, tables, types, mapping).to(torch.float32)
             # CSR by bead: entries (term << 2 | slot) sorted by (bead, term, slot)
             ent = (torch.arange(n_terms).view(1, -1) * 4 + torch.arange(order).view(-1, 1)).flatten()
             bead = mapping.flatten()
@@ -165,7 +185,8 @@ class StaticPriors:
         ``state_dict`` -- a dict, an ``.npz`` or a weights-only ``torch.load`` file -- plus the index mappings
         ``topology[name]`` [order, M] (global bead indices of the collated batch: ``data.neighbor_list[name]
         ["index_mapping"]``), bead types [N] and mol_ptr [B+1] on the CPU.  Every prior in the file needs its mapping;
-        two priors of one kind (e.g. two bond models) are not condensed into one here and raise."""
+        several priors of one kind (two bond models under different names, ...) are condensed into one term list as the
+        reference does (``from_tables``)."""
         if isinstance(sd, str):
             from .schnet import _state_dict_from_file
 
@@ -175,9 +196,7 @@ class StaticPriors:
         for name, (kind, tables) in found.items():
             if name not in topology:
                 raise KeyError(f"prior {name!r} ({kind}) is in the state_dict but topology has no index mapping for it")
-            if kind in spec:
-                raise ValueError(f"two priors of kind {kind!r} in one state_dict")
-            spec[kind] = (tables, topology[name].to(torch.int64))
+            spec.setdefault(kind, []).append((tables, topology[name].to(torch.int64)))
         return cls.from_tables(spec, types, mol_ptr)
 
     def to(self, device):

@@ -29,7 +29,7 @@ extern "C" {
 #define FMD_ELAUNCH (-2)    /* HIP reported a launch error */
 #define FMD_ECAPACITY (-3)  /* a fixed-capacity buffer was too small (reported by the *_status call) */
 #define FMD_EUNSUPPORTED (-4)
-#define FMD_ENONFINITE (-5) /* a force contribution was Inf / NaN / >= 2^31 (reported in the sticky status word) */
+#define FMD_ENONFINITE (-5) /* a force contribution was Inf / NaN / >= 2^19 (reported in the sticky status word) */
 
 const char* fmd_strerror(int code);
 /* ABI version of this library (bumped on any change a caller can observe).
@@ -164,11 +164,16 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
  * Whole-path engine: energy[B] and forces[N,3] of a batch in one call, no [E,F] tensor in HBM.
  * Replaces SchNet.forward (models/schnet.py:178-369) + GradientsOut.forward
  * (models/gradients.py:226-290) for StandardSchNet models (Gaussian basis, cosine cutoff with
- * lower bound 0, tanh, hidden = filters = 128).
+ * lower bound 0, tanh).  The kernels are built for hidden = filters = 128: the caller passes weights zero-padded to
+ * that width (narrower layers are exact under zero padding: a padded feature is 0 in every layer; the Python host
+ * pads hidden, filters <= 128 by itself) and 2 <= num_rbf <= 64.
  *   Weights are packed once by fmd_schnet_pack_bytes / fmd_schnet_pack (device buffer).
- *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as
- *   fp16 hi + lo/2048 and a.b = hi.hi + (hi.lo + lo.hi)/2048 on v_mfma_f32_32x32x16_f16 with fp32
- *   accumulation -- relative error 2e-7, the same as fp32 MFMA, at 3/16 of its MFMA cycles);
+ *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as two fp16
+ *   words, a.b = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- relative error 2e-7,
+ *   the same as the fp32 MFMA, at 3/16 of its MFMA cycles.  Operands of bounded magnitude (weights, Gaussians,
+ *   C*tanh) carry an UNSCALED low word lo = f16(x - hi) -- fp16 denormals are honoured -- and all three products
+ *   share one accumulator; only the unbounded gW operand of the backward u GEMM keeps the scaled form
+ *   lo = f16((x - hi) * 2048) with a second accumulator);
  *   FMD_PREC_W16A16 = the reference's W16A16 mode
  *   (models/gptq.py:92-130,266-306): filter and output networks with fp16 operands (weights =
  *   Linear.weight.half(), activations rounded to fp16 where they are stored), fp32 accumulation.
@@ -177,7 +182,7 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
 #define FMD_PREC_W16A16 1     /* filter and output networks: fp16 operands and stored activations, fp32 accumulate */
 
 typedef struct fmd_schnet_desc {
-  int32_t hidden;        /* = num_filters = 128 */
+  int32_t hidden;        /* = num_filters = 128: the kernels' width (narrower models: zero-padded weights, see above) */
   int32_t num_rbf;       /* R (<= 64) */
   int32_t num_blocks;    /* L */
   int32_t num_out;       /* number of output-network linears (2 or 3) */
@@ -229,8 +234,9 @@ int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64_t n_mol, i
  * beads than max_beads_per_mol: it was truncated to stay inside the LDS sized for that bound -- results are
  * meaningless), [1] = max pairs seen in one molecule, [2] = total pairs: these three are written by every call's last
  * kernel (nothing to zero).  [3] is STICKY: the most negative error code of any call since the caller last zeroed it
- * (the codes of [0], or FMD_ENONFINITE when a force contribution was Inf / NaN / >= 2^31 -- the forces of that
- * molecule are then NaN, never a finite wrong number).  The caller zeroes [3] once and after every read; it may then
+ * (the codes of [0], or FMD_ENONFINITE when a per-pair force contribution was Inf / NaN / >= 2^19 in magnitude -- the
+ * 64-bit fixed-point force sum of a bead takes fewer than 2^12 addends, so below that threshold it cannot wrap; the
+ * forces of that molecule are then NaN, never a finite wrong number).  The caller zeroes [3] once and after every read; it may then
  * read the words every few hundred calls without missing a failed call in between.  forces / energy are fully
  * overwritten.
  * The workspace size does not depend on the current device (it is computed for the largest split any gfx950

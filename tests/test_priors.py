@@ -138,3 +138,49 @@ def test_schnet_plus_priors_nve(golden_dir):
     print(f"SchNet + priors NVE: (max-min of E_tot)/KE = {drift:.2e}")
     assert drift < 2e-2
     assert int(sp.status[3]) == 0
+
+
+def test_several_priors_of_one_kind_are_condensed_like_the_reference(golden_dir):
+    """A SumOut may hold several models of one kind under different names (the reference's GeneralBonds /
+    GeneralAngles); condense_all_priors_for_simulation concatenates their mappings and looked-up parameters and pads
+    Fourier series to the longest expansion (simulation/specialize_prior.py:159-196).  Here: the fixture's bond terms
+    split over two models, its dihedrals over a full-length and a one-term series -- the condensed energy / forces must
+    be the sum of the models evaluated one by one (each of which the fixture pins), from tables and from a
+    state_dict with two bond entries."""
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir)
+    mb, md = maps["bonds"], maps["dihedrals"]
+    hb, hd = mb.shape[1] // 2, md.shape[1] // 3
+    short = {"v_0": tables["dihedrals"]["v_0"], "k1s": tables["dihedrals"]["k1s"][:1], "k2s": tables["dihedrals"]["k2s"][:1]}
+    assert tables["dihedrals"]["k1s"].shape[0] > 1
+
+    def ef(sp):
+        x = pos.double().requires_grad_(True)
+        e = sp.energy_torch(x, ptr)
+        (g,) = torch.autograd.grad(e.sum(), x)
+        return e.detach(), -g
+
+    parts = [prior.StaticPriors.from_tables({"bonds": (tables["bonds"], mb[:, :hb])}, types, ptr),
+             prior.StaticPriors.from_tables({"bonds": (tables["bonds"], mb[:, hb:])}, types, ptr),
+             prior.StaticPriors.from_tables({"dihedrals": (tables["dihedrals"], md[:, :hd])}, types, ptr),
+             prior.StaticPriors.from_tables({"dihedrals": (short, md[:, hd:])}, types, ptr)]
+    e_sum = sum(ef(p)[0] for p in parts)
+    f_sum = sum(ef(p)[1] for p in parts)
+    both = prior.StaticPriors.from_tables({"bonds": [(tables["bonds"], mb[:, :hb]), (tables["bonds"], mb[:, hb:])],
+                                           "dihedrals": [(tables["dihedrals"], md[:, :hd]), (short, md[:, hd:])]},
+                                          types, ptr)
+    assert both.terms["bonds"][0].shape[1] == mb.shape[1] and both.terms["dihedrals"][1].shape[0] == \
+        1 + 2 * tables["dihedrals"]["k1s"].shape[0]
+    e, f = ef(both)
+    assert _rel(e, e_sum) < 1e-12 and _rel(f, f_sum) < 1e-12
+    # the split bonds alone reproduce the fixture's single bond model
+    two = prior.StaticPriors.from_tables({"bonds": [(tables["bonds"], mb[:, :hb]), (tables["bonds"], mb[:, hb:])]}, types, ptr)
+    assert _rel(ef(two)[0], z["bonds_energy_ref64"]) < 1e-6
+    # the same container as a state_dict: two bond entries under different names
+    sd = {"models.bonds_a.model.x_0": tables["bonds"]["x_0"], "models.bonds_a.model.k": tables["bonds"]["k"],
+          "models.bonds_b.model.x_0": tables["bonds"]["x_0"], "models.bonds_b.model.k": tables["bonds"]["k"]}
+    sp = prior.StaticPriors.from_state_dict(sd, {"bonds_a": mb[:, :hb], "bonds_b": mb[:, hb:]}, types, ptr)
+    assert _rel(ef(sp)[0], z["bonds_energy_ref64"]) < 1e-6
+    with pytest.raises(KeyError):
+        prior.StaticPriors.from_state_dict(sd, {"bonds_a": mb[:, :hb]}, types, ptr)
