@@ -481,7 +481,17 @@ def main():
         beta = torch.tensor(betas, device=dev).repeat_interleave(args.batch // args.pt_betas)
         exchange = simulate.LocalReplicaExchange(betas, args.batch // args.pt_betas, args.beads, seed=5)
 
+    drain_ev = torch.cuda.Event()
+
     def barrier():
+        """barrier + torch.cuda.synchronize(), the bracket of every timed region.  The queue is drained by POLLING an
+        event first: a thread that blocks in hipDeviceSynchronize for the 0.2-0.3 s the settle phase has queued up is
+        woken through the kernel driver, and on some boxes that wake-up takes longer than the ~2 ms of idle after which
+        the GPU's clocks need ~20 steps to come back (tools/clock_timeline.py) -- the region then starts slow.  After
+        the poll the two calls below return at once."""
+        drain_ev.record()
+        while not drain_ev.query():
+            pass
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -85,6 +85,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool producer = wave >= 4;   // wave-uniform
   const int w = wave & 3;            // feature slice
+  // (an LDS-only barrier, as the stash variant of the forward kernel needs, makes no difference here: same-box A/B)
+  auto tile_barrier = [&]() { __syncthreads(); };
   int m_own, split;
   wg_to_mol_split(m_own, split);
   const int* wi = a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);  // work items: see the forward kernel
@@ -289,10 +291,10 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         // wrote in the step before, partial sums -> red[i & 1]; after the step's barrier wave 0 adds them up.
         const gw_lds_ptr gw_b1 = gw_a1 + (reinterpret_cast<const char*>(gw_img2f) - reinterpret_cast<const char*>(hid_hi)) / 8;
         const gw_lds_ptr gw_b2 = gw_a2 + (reinterpret_cast<const char*>(gw_img2f) - reinterpret_cast<const char*>(hid_hi)) / 8;
-        __syncthreads();  // P0: fragments of the first two tiles and gW of the first tile visible
+        tile_barrier();  // P0: fragments of the first two tiles and gW of the first tile visible
         frag_cur = frag_l;
         compute(T0 + S, ks_a);  // k of the first tile
-        __syncthreads();  // P1: the first tile's fragments consumed (the consumers replace them in step 0)
+        tile_barrier();  // P1: the first tile's fragments consumed (the consumers replace them in step 0)
         FMD_MARK(11)
         auto ptile = [&](int t, auto odd, KSet& cu, KSet& nx) {
           constexpr bool ODD = decltype(odd)::value;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           float* rbuf = ODD ? red2 : red;
           if (h == 0) rbuf[w * 32 + c32] = tot;
           FMD_MARK(3)
-          __syncthreads();   // the step's only barrier
+          tile_barrier();   // the step's only barrier
           FMD_MARK(4)
           if (w == 0 && h == 0) {
             const float sum = ((rbuf[c32] + rbuf[32 + c32]) + rbuf[64 + c32]) + rbuf[96 + c32];
@@ -316,18 +318,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           ptile(t + S, std::true_type{}, ks_b, ks_a);
         }
       } else {
-      if (SHARE) __syncthreads();  // fragments of the first tile visible
+      if (SHARE) tile_barrier();  // fragments of the first tile visible
       compute(T0 + S, ks_a);
-      if (SHARE) __syncthreads();  // ... and consumed: the consumers write the second tile's
+      if (SHARE) tile_barrier();  // ... and consumed: the consumers write the second tile's
       put();
-      __syncthreads();  // A(first)
+      tile_barrier();  // A(first)
       FMD_MARK(11)
       auto tile = [&](int t, KSet& cu, KSet& nx) {
         if (!FMD_DBG_SKIP(a, 1)) compute(t + 2 * S, nx);  // stages tile t+S while the consumers contract tile t
         FMD_MARK(0)
-        if (!TWO) __syncthreads();     // B(t)
+        if (!TWO) tile_barrier();     // B(t)
         FMD_MARK(1)
-        __syncthreads();     // C(t): gW(t) visible (TWOB: and hidden(t) consumed)
+        tile_barrier();     // C(t): gW(t) visible (TWOB: and hidden(t) consumed)
         FMD_MARK(2)
         if (TWOB) put();     // hidden tile of t+S into its own plane, which the consumers have left
         // u^T slice = W1^T slice . gW^T  (lane = pair, registers = hidden features); dE/dd = C sum_h u (1-h^2) z' + C' sum_h u h
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         if (h == 0) red[w * 32 + c32] = tot;
         FMD_MARK(3)
         if (!TWO) {
-          __syncthreads();     // D(t): gW consumed, partial sums visible
+          tile_barrier();     // D(t): gW consumed, partial sums visible
           FMD_MARK(4)
           if (w == 0 && h == 0) {
             const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           put();               // hidden tiles of t+S
         }
         FMD_MARK(5)
-        __syncthreads();     // A(t+S) (two-barrier forms: also gW(t) consumed, partial sums visible)
+        tile_barrier();     // A(t+S) (two-barrier forms: also gW(t) consumed, partial sums visible)
         FMD_MARK(6)
         if (TWO && w == 0 && h == 0) {   // (red is next written after C(t+S), which this wave reaches after the read)
           const float sum = ((red[c32] + red[32 + c32]) + red[64 + c32]) + red[96 + c32];
@@ -506,8 +508,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         fill();                        // X <- second tile
         fetch_meta(T0 + 2 * S);
         fetch_d(T0 + 2 * S);
-        __syncthreads();  // P0
-        __syncthreads();  // P1
+        tile_barrier();  // P0
+        tile_barrier();  // P1
         FMD_MARK(11)
         bool odd = false;
         for (int t = T0; t < t_end; t += S, odd = !odd) {
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           fetch_meta(t + 3 * S);
           fetch_d(t + 3 * S);
           FMD_MARK(5)
-          __syncthreads();  // the step's only barrier
+          tile_barrier();  // the step's only barrier
           FMD_MARK(8)
         }
       } else {
@@ -530,22 +532,22 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       fetch_d(T0 + S);
       fetch_meta(T0 + S);
       if (SHARE) {
-        __syncthreads();  // first tile's fragments visible
-        __syncthreads();  // ... and consumed
+        tile_barrier();  // first tile's fragments visible
+        tile_barrier();  // ... and consumed
         share_fragments();
       }
       form_gw();  // first tile
       if (slice_owner) fetch_w(T0);
-      __syncthreads();  // A(first)
+      tile_barrier();  // A(first)
       FMD_MARK(11)
       for (int t = T0; t < t_end; t += S) {
         fetch_d(t + 2 * S);  // for the fragments written after C(t)
         if (!slice_owner) {  // FS, waves 2 and 3: distances for the shared Gaussians and the barrier protocol
-          if (!TWO) __syncthreads();  // B(t)
-          __syncthreads();  // C(t)
+          if (!TWO) tile_barrier();  // B(t)
+          tile_barrier();  // C(t)
           if (SHARE) share_fragments();
-          if (!TWO) __syncthreads();  // D(t)
-          __syncthreads();  // A(t+S)
+          if (!TWO) tile_barrier();  // D(t)
+          tile_barrier();  // A(t+S)
           continue;
         }
         f32x16 fl = zero16();
@@ -641,20 +643,20 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         fetch_w(t + S);
         FMD_MARK(6)
         }
-        if (!TWO) __syncthreads();  // B(t): hidden tiles consumed
+        if (!TWO) tile_barrier();  // B(t): hidden tiles consumed
         FMD_MARK(2)
         gw_store(gw_base);
         FMD_MARK(3)
-        __syncthreads();  // C(t): gW visible
+        tile_barrier();  // C(t): gW visible
         FMD_MARK(4)
         // the producers read fragments only while staging (between A and B): the tile they stage in the
         // next iteration, t + 2S, is written here
         if (SHARE) share_fragments();
         form_gw();  // tile t+S
         FMD_MARK(7)
-        if (!TWO) __syncthreads();  // D(t)
+        if (!TWO) tile_barrier();  // D(t)
         FMD_MARK(8)
-        __syncthreads();  // A(t+S)
+        tile_barrier();  // A(t+S)
         FMD_MARK(9)
       }
       }  // !PIPE

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   // vmcnt(0): with the stash stores in flight that is an HBM write round trip per tile (measured: +46 us per launch).
   auto tile_barrier = [&]() {
     if constexpr (STASH) lds_barrier();
-    else __syncthreads();
+    else __syncthreads();   // (LDS-only barriers in the other variants: same-box A/B, no difference)
   };
   int m_own, split;
   wg_to_mol_split(m_own, split);
