@@ -42,8 +42,13 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   // tile is double-buffered -- the producers write tile t+S into the plane the consumers are not reading, and ONE barrier
   // per tile ("tile t+S visible, tile t consumed") replaces the pair A / B: with a third of the MFMA work the two
   // barriers and the serial put between them were a fifth of the tile.
-  constexpr bool DB = HALF && !FS && !SH;
-  float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B
+  constexpr bool DB = HALF && !FS;
+  // DBS (W16A16 with shared Gaussians): two fragment buffers of [nb][32] x 16 B (one fp16 record per half k-step) that
+  // alternate like the hidden planes.  In this precision the SIMDs are issue-bound (per tile ~450 VALU, 64
+  // transcendentals, 12 MFMA: the sum of both roles' streams IS the tile), and each producer forming ALL Gaussians of
+  // its pairs was a quarter of that stream.
+  constexpr bool DBS = DB && SH;
+  float* frag_l = smem + TILE_FLOATS + 128;                      // SH: [nb][hi, lo][32] x 16 B  (DBS: 2 x [nb][32] x 16 B)
   float* agg = smem + TILE_FLOATS + 128 + (SH ? a.nb * 256 : 0); // [n][128]
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const bool producer = wave >= 4;   // wave-uniform
@@ -108,6 +113,10 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h) * (2.0f * LOG2E);
       float d_n = pdist[min(T0 * 32, last_base) + c32], c_n = pcut[min(T0 * 32, last_base) + c32];
       f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
+      float* const frag_b0 = frag_l;                 // DBS: the two fragment buffers ...
+      float* const frag_b1 = frag_l + a.nb * 128;
+      const float* frag_rd_buf = frag_b0;            // ... and the one compute() reads
+      (void)frag_b1; (void)frag_rd_buf;
       auto compute = [&](int t_next) {
         const float d = d_n, C = c_n, C2 = c_n * (2.0f * LOG2E);
         const int nb = min(t_next * 32, last_base);
@@ -118,6 +127,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           // the fragments of k-step s+1 are requested before the MFMAs of k-step s
           auto frag_rd = [&](int s_, int rec) {
             const int blk = min(2 * s_ + h, a.nb - 1);  // past the last Gaussian: any finite data (zero weights)
+            if constexpr (DBS) return *reinterpret_cast<const f16x8*>(frag_rd_buf + (blk * 32 + c32) * 4);
             return *reinterpret_cast<const f16x8*>(frag_l + ((blk * 2 + rec) * 32 + c32) * 4);
           };
           f16x8 bh = frag_rd(0, 0), bl = bh;
@@ -193,6 +203,18 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           if (!HALF) *reinterpret_cast<f16x8*>(frag_l + ((blk * 2 + 1) * 32 + c32) * 4) = fr_l;
         }
       };
+      auto put_frags_to = [&](float* buf) {   // DBS: one record per half k-step
+        if (shares) *reinterpret_cast<f16x8*>(buf + ((2 * w + h) * 32 + c32) * 4) = fr_h;
+      };
+      if constexpr (DBS) {
+        gauss();                 // first tile (d_n as fetched above)
+        put_frags_to(frag_b0);
+        tile_barrier();          // its fragments visible
+        frag_rd_buf = frag_b0;
+        compute(T0 + S);         // stages the first tile; d_n <- second tile
+        gauss();                 // second tile
+        put_frags_to(frag_b1);
+      } else {
       if (SH) {
         gauss();          // first tile (d_n as fetched above)
         put_frags();
@@ -204,15 +226,21 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         tile_barrier();  // the first tile's fragments consumed
         put_frags();
       }
+      }
       put();
       tile_barrier();  // A(first)
       FMD_MARK(11)
       if constexpr (DB) {
         int par = 1;
         for (int t = T0; t < t_end; t += S, par ^= 1) {
+          // DBS, step i (par = (i + 1) & 1): tile t+S is staged from the fragments in buffer `par` (written one step
+          // ago), the fragments of t+2S go into the other buffer, whose last reader was the compute() of the step before
+          if constexpr (DBS) frag_rd_buf = par ? frag_b1 : frag_b0;
           compute(t + 2 * S);  // tile t+S, while the consumers work on tile t ...
+          if constexpr (DBS) gauss();   // tile t+2S (d_n holds its distances now)
           FMD_MARK(0)
           put_to(par ? hid_lo : hid_hi);  // ... into the plane they are not reading
+          if constexpr (DBS) put_frags_to(par ? frag_b0 : frag_b1);
           FMD_MARK(2)
           tile_barrier();     // tile t+S visible, tile t consumed
           FMD_MARK(3)
@@ -321,7 +349,9 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       // The aggregate update of a tile is deferred by one tile: it does not depend on the hidden
       // tile, so it runs (with the refill of X) while the producers stage the next tile, instead of
       // between the two barriers where the producers only write LDS.
-      if (SH) {  // the producers' fragment hand-over (see there): two more barriers before the first tile
+      if (DBS) {        // the producers' fragment hand-over (see there): one more barrier before the first tile ...
+        tile_barrier();
+      } else if (SH) {  // ... two in the two-barrier form
         tile_barrier();
         tile_barrier();
       }
@@ -462,7 +492,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 namespace fmd_eng {
 
 #define FMD_FWD_ALL(M_)                                                                            \
-  M_(false, false, false) M_(true, false, false) M_(false, true, false) M_(true, true, false) M_(false, false, true)
+  M_(false, false, false) M_(true, false, false) M_(false, true, false) M_(true, true, false) M_(false, false, true) \
+  M_(true, false, true)
 
 template <int NS0, bool STASH>
 static int set_fwd_attrs() {
@@ -487,10 +518,9 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   // [tile region][red 128][centres 64][bias 128][aggregate rows] (the backward kernel's carve: one size for both)
   const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
   // shared-Gaussian form when its fragment region fits next to the aggregate
-  // (not in W16A16: without operand splits the Gaussians are cheap for the producers, and the consumers' extra work
-  //  between B and A costs more than it saves: 0.156 vs 0.144 ms)
+  // W16A16: [tile region = two hidden planes][two fragment buffers of nb x 512 B][aggregate rows] (the same size)
   const size_t lds_sh = (size_t)(TILE_FLOATS + 128 + a.nb * 256 + a.max_beads * F) * sizeof(float);
-  const bool sh = !a.fs && !half && lds_sh <= MAX_LDS_BYTES;
+  const bool sh = !a.fs && lds_sh <= MAX_LDS_BYTES;
   if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
 #define FMD_ONE(H_, FS_, SH_)                                                                     \
   if (half == H_ && a.fs == FS_ && sh == SH_) {                                                   \

@@ -81,11 +81,14 @@ def _output_weights(on):
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True):
+    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True,
+                 tabulated_filter: bool = False):
         """``precision``: "f32" (default) or "w16a16"; a model whose filter and output networks
         were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself.  ``filter_stash=False``: the
         backward pair kernels recompute filter layer 1 instead of reading the values the forward kernels kept
-        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits)."""
+        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits).  ``tabulated_filter=True`` (opt-in, fp32
+        only): the filter network of every block is tabulated over the pair distance when the weights are packed and
+        the pair kernels interpolate it (FMD_FLAG_TABULATED_FILTER) instead of evaluating it on the MFMA."""
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -137,7 +140,7 @@ class FusedSchNetEngine:
             raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
         d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
-        d.flags = 0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH
+        d.flags = (0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH) | (_ffi.FLAG_TABULATED_FILTER if tabulated_filter else 0)
         self.desc = d
 
         # host copies of the weights (fp32, contiguous) -> packed register-order buffer -> device

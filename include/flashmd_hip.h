@@ -204,6 +204,12 @@ typedef struct fmd_schnet_desc {
  * layer 1.  With this flag the workspace stays small and the backward pass recomputes (same results to the last bit:
  * the recomputation runs the same arithmetic). */
 #define FMD_FLAG_NO_FILTER_STASH 1
+/* Opt-in, FMD_PREC_F32 only: the message weight of a block, W(d) = filt(rbf(d)) C(d), is a function of the pair distance
+ * alone once the weights are frozen; fmd_schnet_pack tabulates it (one cubic per interval of width 2^e, 1024..2047
+ * intervals over [0, cutoff], fp64 evaluation of the filter network and its analytic slope; pack_bytes grows by
+ * intervals * 2 KB per block) and the pair kernels interpolate instead of running the filter network on the MFMA.
+ * Interpolation error ~1e-8 relative at the 1ENH basis.  Never the default: the reference's arithmetic is the MFMA path. */
+#define FMD_FLAG_TABULATED_FILTER 2
 
 /* Host pointers to the reference's parameter tensors (fp32, nn.Linear [out,in] layout). */
 typedef struct fmd_schnet_block_weights {

@@ -919,3 +919,24 @@ def test_captured_timestep_is_bit_identical(params, precision, steps_per_graph):
     graph.release_graph()
     eager.timestep(); graph.timestep()
     assert torch.equal(eager.x, graph.x)
+
+
+@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
+def test_tabulated_filter_mode_vs_reference_vectors(params, golden_dir, case):
+    """Opt-in FMD_FLAG_TABULATED_FILTER: the pair kernels interpolate W(d) = filt(rbf(d)) C(d) from the table packed
+    with the weights (csrc/fmd_engine_tab.hip) instead of running the filter network on the MFMA.  Same golden vectors,
+    same bar as the MFMA formulation: forces <= 2e-5 against the reference's fp64 result."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    z = np.load(os.path.join(golden_dir, case + ".npz"))
+    pos, types, ptr = (torch.from_numpy(z[k]).to(DEV) for k in ("pos", "types", "ptr"))
+    model = S.model_from_params(params).to(DEV)
+    eng = engine.FusedSchNetEngine(model, tabulated_filter=True)
+    mb = int((ptr[1:] - ptr[:-1]).max())
+    e, f = eng.energy_forces(pos, types, ptr, mb)
+    re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
+    print(f"{case}: tabulated filter, energy {re:.2e} forces {rf:.2e}")
+    assert re < 2e-5 and rf < 2e-5
+    e2, f2 = eng.energy_forces(pos, types, ptr, mb)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
