@@ -583,8 +583,9 @@ def main():
             pt_info["rank0_bytes_sent_timed"] = exchange.bytes_sent - bytes_before
             pt_info["rank0_payload_transfers_total"] = exchange.payload_transfers
             pt_info["bytes_per_attempt_note"] = (f"energies {4 * args.batch} B one way, accept mask {args.batch} B back; "
-                                                 f"positions+velocities {2 * args.batch * args.beads * 12} B each way "
-                                                 "only when a pair was accepted")
+                                                 f"positions+velocities+forces {3 * args.batch * args.beads * 12} B and the "
+                                                 f"energies ({4 * args.batch} B) each way only when a pair was accepted; "
+                                                 "no force evaluation in an exchange (forces travel with their configuration)")
 
     # ---- W16A16 leg (BASELINE configs[2]) on the same batch, after the fp32 regions
     w16 = None

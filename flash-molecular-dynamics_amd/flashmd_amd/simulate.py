@@ -433,9 +433,13 @@ class DistributedReplicaExchange:
     its energies (n_indep floats), the lower rank draws the uniform numbers (a CPU generator keyed by
     (seed, attempt, lower rank); the reference draws from the global CPU RNG, parallel_tempering.py:394),
     decides, and sends the accept mask back (n_indep bytes) -- two ranks can never disagree on a
-    borderline ``rand < p`` and then wait for a transfer the other never posts.  Positions+velocities of
-    the batch (fixed size, <= 0.83 MB at 128 x 269 beads) cross the link, once each way, only when at
-    least one pair was accepted, and are applied where the mask says so."""
+    borderline ``rand < p`` and then wait for a transfer the other never posts.  Positions, velocities AND
+    forces of the batch (fixed size, <= 1.24 MB at 128 x 269 beads, plus the energies) cross the link, once each
+    way, only when at least one pair was accepted, and are applied where the mask says so.  The forces travel with
+    the configuration they were computed for: F(x) depends on the replica's own coordinates only (one model for all
+    temperatures), so nothing is re-evaluated after an exchange -- the reference keeps the pre-exchange forces until
+    the next timestep's force call (parallel_tempering.py:415-481), which gives the exchanged replicas one half-kick
+    with the other configuration's forces; moving the forces costs 0.4 MB per way and none of that."""
 
     def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0, group=None):
         import torch.distributed as dist
@@ -509,20 +513,21 @@ class DistributedReplicaExchange:
         if self.rank == lo:
             pt_count(self.local_matrix, lo, hi, n_acc, self.n_indep)
         if n_acc:
-            # 3. positions and velocities of the whole batch cross the link once, each way
-            incoming = self._swap(torch.stack([sim.x, sim.v]).contiguous(), peer)
+            # 3. positions, velocities and forces of the whole batch (and the energies) cross the link once, each way
+            incoming = self._swap(torch.stack([sim.x, sim.v, sim.f]).contiguous(), peer)
+            u_peer_all = self._swap(u_mine, peer)
             self.payload_transfers += 1
             # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
             #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
             mask = acc.repeat_interleave(self.n_atoms)[:, None]
             scale = math.sqrt(self.betas[self.rank] / self.betas[peer])
-            sim.x = torch.where(mask, incoming[0], sim.x).contiguous()
-            sim.v = torch.where(mask, incoming[1] * scale, sim.v).contiguous()
-            # forces/energies of the swapped replicas belong to the other temperature's coordinates:
-            # re-evaluate so the next B half-kick uses forces at the new positions (the reference keeps
-            # stale forces until the next timestep's force call; re-evaluating is the conservative choice).
-            # Nothing accepted: nothing moved, nothing to re-evaluate.
-            sim.energy, sim.f = sim.force_fn(sim.x)
+            # (in place: a captured hipGraph keeps reading and writing these buffers)
+            sim.x.copy_(torch.where(mask, incoming[0], sim.x))
+            sim.v.copy_(torch.where(mask, incoming[1] * scale, sim.v))
+            # forces and energies belong to the coordinates they were computed for and move with them: the next B
+            # half-kick uses the forces AT the new positions without a force evaluation
+            sim.f.copy_(torch.where(mask, incoming[2], sim.f))
+            sim.energy.copy_(torch.where(acc, u_peer_all, sim.energy))
         self.exchange_seconds += time.perf_counter() - t0
         self.exchanges += 1
 
@@ -556,6 +561,7 @@ class LocalReplicaExchange:
         self.gen = torch.Generator().manual_seed(seed)
         self.attempt = 0
         self.acceptance_matrix = torch.zeros(len(self.betas), len(self.betas), dtype=torch.int64)
+        self._scratch = None
 
     def __call__(self, sim: "LangevinSimulation"):
         even = self.attempt % 2 == 0
@@ -575,4 +581,12 @@ class LocalReplicaExchange:
             pt_count(self.acceptance_matrix, a, b, int(n_acc), self.n_indep)
         if sum(per_pair):
             pt_swap_local(sim.x, sim.v, mol_a, mol_b, acc, beta, self.n_atoms)
-            sim.energy, sim.f = sim.force_fn(sim.x)
+            # forces and energies travel with their configuration (F depends on the replica's own coordinates only):
+            # the same in-batch swap on the force rows -- its velocity argument is a scratch array -- and a masked swap
+            # of the energies; no force evaluation (see DistributedReplicaExchange)
+            if self._scratch is None or self._scratch.shape != sim.f.shape:
+                self._scratch = torch.zeros_like(sim.f)
+            pt_swap_local(sim.f, self._scratch, mol_a, mol_b, acc, beta, self.n_atoms)
+            ea, eb, m = sim.energy[mol_a], sim.energy[mol_b], acc.bool()
+            sim.energy[mol_a] = torch.where(m, eb, ea)
+            sim.energy[mol_b] = torch.where(m, ea, eb)

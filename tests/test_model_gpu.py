@@ -940,3 +940,40 @@ def test_tabulated_filter_mode_vs_reference_vectors(params, golden_dir, case):
     assert re < 2e-5 and rf < 2e-5
     e2, f2 = eng.energy_forces(pos, types, ptr, mb)
     assert torch.equal(e, e2) and torch.equal(f, f2)
+
+
+def test_local_replica_exchange_moves_forces_with_the_configurations(params):
+    """Parallel tempering with all temperatures in one batch (the reference's layout, parallel_tempering.py:204-220):
+    an exchange swaps positions, rescaled velocities (reference :467-477) AND the forces / energies of the accepted
+    pairs -- F(x) depends on the replica's own coordinates only, and the engine's result for a molecule does not
+    depend on its place in the batch -- so afterwards the stored forces are, bit for bit, what a force evaluation at the
+    new positions returns, without one having been made."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, simulate
+
+    n_betas, n_indep, A = 4, 2, 37
+    pos, types, ptr = so.synth_batch(n_betas * n_indep, A, 5.0)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    calls = [0]
+
+    def force(x):
+        calls[0] += 1
+        return eng.energy_forces(x, T, Q, A)
+
+    betas = [1.67, 1.3, 1.0, 0.8]
+    beta = torch.tensor(betas, device=DEV).repeat_interleave(n_indep)
+    sim = simulate.LangevinSimulation(force, P, torch.full((P.shape[0],), 12.0, device=DEV), beta, A, seed=3)
+    ex = simulate.LocalReplicaExchange(betas, n_indep, A, seed=1)
+    moved = 0
+    for attempt in range(6):
+        for _ in range(3):
+            sim.timestep()
+        x_before, n_calls = sim.x.clone(), calls[0]
+        ex(sim)
+        assert calls[0] == n_calls                       # no force evaluation inside an exchange
+        moved += int(not torch.equal(x_before, sim.x))
+        e_chk, f_chk = eng.energy_forces(sim.x, T, Q, A)
+        assert torch.equal(sim.f, f_chk) and torch.equal(sim.energy, e_chk)
+    m = ex.acceptance_matrix
+    assert moved >= 1 and int(m.sum()) == n_indep * (3 * 2 + 3 * 1)   # (0,1),(2,3) x 3 even; (1,2) x 3 odd attempts

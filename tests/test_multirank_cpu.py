@@ -77,6 +77,8 @@ elif mode == "pt":
     x_exp = torch.where(mask, allx[peer], allx[rank])
     v_exp = torch.where(mask, allv[peer] * math.sqrt(betas[rank] / betas[peer]), allv[rank])
     ok = torch.equal(sim.x, x_exp) and torch.allclose(sim.v, v_exp)
+    e_chk, f_chk = sim.force_fn(sim.x)   # forces and energies moved with the configurations
+    ok = ok and torch.allclose(sim.f, f_chk, rtol=1e-4, atol=1e-5) and torch.allclose(sim.energy, e_chk, rtol=1e-5, atol=1e-5)
     a_, t_ = ex.acceptance()
     # one write per rank: the two ranks share a pipe and print() of several arguments can interleave
     sys.stdout.write(f"PT_OK {int(ok)} {int(acc.sum())} {int(a_[0])} {int(t_[0])}\n")
@@ -135,8 +137,12 @@ elif mode in ("pt4", "pt8"):
                 v_exp = torch.where(mask, allv[peer] * math.sqrt(betas[rank] / betas[peer]), allv[rank])
                 moved = bool(acc.any())
         ok = ok and torch.equal(sim.x, x_exp) and torch.allclose(sim.v, v_exp)
-        # forces are re-evaluated only where something was accepted (idle ranks and all-rejected pairs: not)
-        ok = ok and (counted[0] - before == (1 if moved else 0))
+        # an exchange never evaluates forces: they (and the energies) travel with their configuration ...
+        ok = ok and (counted[0] - before == 0)
+        # ... and are the forces AT the new positions
+        e_chk, f_chk = inner(sim.x)
+        ok = ok and torch.allclose(sim.f, f_chk, rtol=1e-4, atol=1e-5) and torch.allclose(sim.energy, e_chk, rtol=1e-5, atol=1e-5)
+        ok = ok and (moved or torch.equal(sim.x, allx[rank]))
     m = ex.acceptance_matrix()
     n_even, n_odd = (n_attempts + 1) // 2, n_attempts // 2
     ok = ok and torch.equal(m, expected) and int(m.sum()) == n_indep * (n_even * (world // 2) + n_odd * ((world - 1) // 2))
@@ -209,8 +215,8 @@ def test_parallel_tempering_exchange_eight_ranks_the_bench_ladder():
     """BASELINE configs[4] without the hardware: eight ranks over gloo, the ladder of eight temperatures that
     `bench.py --pt --gpus 8` builds, both phases twice; every attempt against the expectation from the gathered
     pre-exchange state, the acceptance matrix against the reference's bookkeeping
-    (simulation/parallel_tempering.py:99-104,407-412), idle end ranks in the odd phase, no force re-evaluation without
-    an accepted pair."""
+    (simulation/parallel_tempering.py:99-104,407-412), idle end ranks in the odd phase, no force evaluation in an exchange
+    (forces and energies travel with their configuration)."""
     out = _run("pt8", nproc=8)
     import re
 
