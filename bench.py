@@ -88,6 +88,7 @@ def parse(argv=None):
     ap.add_argument("--no-filter-stash", action="store_true",
                     help="FMD_FLAG_NO_FILTER_STASH: the backward pair kernels recompute filter layer 1 instead of reading "
                          "the forward kernels' values back (A/B of the stash; same results)")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the hipGraph replay leg (profiler runs)")
     ap.add_argument("--pt", action="store_true", help="parallel tempering (BASELINE configs[4])")
     ap.add_argument("--exchange-interval", type=int, default=100, help="reference examples/parallel_tempering.yaml:11")
     ap.add_argument("--pt-betas", type=int, default=8, help="temperatures in the batch when --pt runs on one GPU")
@@ -543,7 +544,7 @@ def main():
     # the reference's torch.compile wrapper).  Reported beside the line, never as `value`: the events that time the
     # dominant kernel are recorded by the un-captured path.
     graph_info = None
-    if not args.pt and world == 1:
+    if not args.pt and world == 1 and not args.no_graph_leg:
         st = leg.save_state()
         sim.capture()
         k_g = min(max(args.steps, 20), 200)

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/trace_$TAG
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-w16a16-leg "$@" > $OUT/bench_line.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-w16a16-leg --no-graph-leg "$@" > $OUT/bench_line.json 2> $OUT/err.txt
 find $OUT/t -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/t
 python3 - $OUT/kernel_stats.csv <<'PY'
