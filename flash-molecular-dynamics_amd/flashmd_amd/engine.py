@@ -27,6 +27,7 @@ MAX_BEADS = 535   # 283 with the whole aggregate in one workgroup's LDS, 535 in 
 PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, fp32-grade (2e-7 per contraction), the default
               "w16a16": 1}     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
 STATUS_CHECK_EVERY = 1024      # force evaluations between two reads of the device status words (one sync each)
+MAX_STASH_BYTES = 48 << 30     # a batch whose filter stash would exceed this runs without it (same results, slower)
 
 
 def _linears(mlp):
@@ -141,6 +142,7 @@ class FusedSchNetEngine:
         d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
         d.flags = (0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH) | (_ffi.FLAG_TABULATED_FILTER if tabulated_filter else 0)
+        self._flags = d.flags   # as requested; _workspace() may add FMD_FLAG_NO_FILTER_STASH for a very large batch
         self.desc = d
 
         # host copies of the weights (fp32, contiguous) -> packed register-order buffer -> device
@@ -197,6 +199,13 @@ class FusedSchNetEngine:
     def _workspace(self, n_mol, n_nodes, cap):
         key = (n_mol, n_nodes, cap)
         if self._ws_key != key:
+            # the filter stash is sized for the worst-case pair list (n_mol * cap * 512 bytes per block but the first):
+            # batches for which that would be unreasonable fall back to recomputation in the backward pass
+            self.desc.flags = self._flags
+            stash = (self.desc.num_blocks - 1) * n_mol * cap * 512
+            if self.desc.precision == PRECISIONS["f32"] and not (self._flags & _ffi.FLAG_NO_FILTER_STASH) \
+                    and stash > MAX_STASH_BYTES:
+                self.desc.flags = self._flags | _ffi.FLAG_NO_FILTER_STASH
             nbytes = _ffi.lib().fmd_schnet_workspace_bytes(ctypes.byref(self.desc), n_mol, n_nodes, cap)
             if nbytes <= 0:
                 raise RuntimeError("fmd_schnet_workspace_bytes failed")
