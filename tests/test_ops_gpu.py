@@ -94,9 +94,10 @@ def test_radius_graph_pairs_within_an_ulp_of_the_cutoff(K, golden_dir):
 
 
 # ---------------------------------------------------------------------------------------- A2
-def test_distance_rbf_forward_and_backward(K):
+@pytest.mark.parametrize("R", [50, 7, 64, 100])   # 100: more columns than one staging pass of the backward kernel (61)
+def test_distance_rbf_forward_and_backward(K, R):
     pos, _, ptr, src, dst = _graph()
-    centers, gamma = so.rbf_centers(50, 5.0)
+    centers, gamma = so.rbf_centers(R, 5.0)
     p64 = pos.double().requires_grad_(True)
     d_ref = so.compute_distances(p64, src, dst)
     rbf_ref = so.gaussian_rbf(d_ref, centers.double(), gamma, 5.0)
@@ -127,7 +128,7 @@ def test_distance_rbf_forward_and_backward(K):
     # zero edges: empty outputs (reference cfconv_kernels.py:1630-1631)
     e0 = torch.zeros(0, dtype=torch.int64, device=DEV)
     d0, r0 = K.fused_distance_gaussian_rbf_cutoff(pos.to(DEV), e0, e0, centers.to(DEV), gamma, 5.0)
-    assert d0.shape == (0,) and r0.shape == (0, 50)
+    assert d0.shape == (0,) and r0.shape == (0, R)
 
 
 # ---------------------------------------------------------------------------------------- A3
