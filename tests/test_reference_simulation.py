@@ -167,3 +167,33 @@ def test_force_provider_from_sumout_state_dict_matches_the_reference_container(s
     print(f"SumOut state_dict: total energy {re:.2e} forces {rf:.2e}; SchNet forces {rs:.2e}; prior forces {rp:.2e}")
     assert re < 1e-4 and rf < 1e-4 and rs < 1e-4 and rp < 1e-4
     assert rf < 2e-5 and rs < 2e-5 and rp < 2e-5   # where fp32 actually lands
+
+
+@pytest.mark.gpu
+def test_captured_timestep_with_the_full_force_provider(sumout):
+    """The hipGraph of a timestep over the WHOLE force provider of row N4 (fused engine + the four condensed prior
+    kernels, built from the reference container's state_dict): ten replayed steps equal ten un-captured ones bit for bit,
+    and the provider's status words are still readable afterwards."""
+    from flashmd_amd import simulate
+
+    z, sd, topo = sumout
+    dev = "cuda:0"
+    types, ptr = torch.from_numpy(z["types"]), torch.from_numpy(z["ptr"])
+    pos = torch.from_numpy(z["pos"]).to(dev)
+    masses = torch.full((pos.shape[0],), 12.0, device=dev)
+    beta = torch.full((N_SIMS,), 1.67, device=dev)
+
+    def make():
+        fn = simulate.force_fn_from_state_dict(sd, types, ptr, topology=topo, device=dev)
+        return simulate.LangevinSimulation(fn, pos, masses, beta, N_ATOMS, dt=0.002, friction=1.0, seed=5)
+
+    eager, graph = make(), make()
+    graph.capture()
+    for _ in range(10):
+        eager.timestep()
+        graph.timestep()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eager.x).all()
+    assert torch.equal(eager.x, graph.x) and torch.equal(eager.v, graph.v)
+    assert torch.equal(eager.f, graph.f) and torch.equal(eager.energy, graph.energy)
+    graph.check_status()
