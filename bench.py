@@ -668,6 +668,12 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / prec["peak"],
                          "traffic": traffic if args.precision == "f32" else None,
                          "traffic_source": traffic_src if args.precision == "f32" else None,
+                         "traffic_note": (None if args.precision != "f32" or args.no_filter_stash else
+                                          "edge_bwd averages 507 MB per launch because two of its three launches read the "
+                                          "filter stash back (482 MB each: the forward kernel's filter values, kept instead "
+                                          "of recomputing filter layer 1 -- a compute-for-traffic trade measured at +5 % "
+                                          "throughput, DESIGN.md section 3 'Round 4'); --no-filter-stash recomputes: 158 MB, "
+                                          "0.29 ms per launch"),
                          "peak_note": prec["note"],
                          "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": dom_ms,
                          "launches_per_step": leg.launches[leg.dom]},
