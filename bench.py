@@ -92,6 +92,9 @@ def parse(argv=None):
     ap.add_argument("--pt", action="store_true", help="parallel tempering (BASELINE configs[4])")
     ap.add_argument("--exchange-interval", type=int, default=100, help="reference examples/parallel_tempering.yaml:11")
     ap.add_argument("--pt-betas", type=int, default=8, help="temperatures in the batch when --pt runs on one GPU")
+    ap.add_argument("--pt-forces", default="reference", choices=["reference", "moved"],
+                    help="reference = positions and rescaled velocities are exchanged, forces stay (the reference's "
+                         "trajectory, simulation/parallel_tempering.py:415-481); moved = forces and energies travel too")
     return ap.parse_args(argv)
 
 
@@ -159,10 +162,24 @@ class HipEvents:
         return ms.value
 
 
-def cpu_baseline(model, args):
+def parity_record(e, f, e_ref, f_ref, n_mol, bar, against):
+    """All `n_mol` molecules of the bench batch against the CPU oracle at the same start positions (outside every timed
+    region): energies max|dE| / max|E|, forces relative L2 over the batch and for the worst single molecule."""
+    e, f, e_ref, f_ref = e.double(), f.double(), e_ref.double(), f_ref.double()
+    per_mol = ((f - f_ref).view(n_mol, -1).norm(dim=1) / f_ref.view(n_mol, -1).norm(dim=1))
+    rec = {"energy_rel": float((e - e_ref).abs().max() / e_ref.abs().max()),
+           "forces_rel": float((f - f_ref).norm() / f_ref.norm()),
+           "forces_rel_worst_molecule": float(per_mol.max()), "molecules": n_mol, "bar": bar, "against": against}
+    rec["within_bar"] = bool(rec["energy_rel"] < bar and rec["forces_rel_worst_molecule"] < bar)
+    return rec
+
+
+def cpu_baseline(model, args, engine_results=None):
     """The CPU oracle (a port of the reference's --disable_optim PyTorch path) timed on this node's host cores at
     BASELINE configs[0]'s size (B = 4) and at the GPU line's size (B = --batch), >= 3 force evaluations each after a
-    warm-up, same throughput definition."""
+    warm-up (SURVEY.md 8d), same throughput definition.  `engine_results`: {"f32": (energy, forces), "w16a16": ...}
+    of the engines at the bench batch's START positions (CPU tensors) -- the oracle then also evaluates that batch once
+    in fp64 (and once through its W16A16 restatement) and the record carries `parity` over all its molecules."""
     from oracle import schnet_oracle as so
     from flashmd_amd import synthetic
 
@@ -193,11 +210,34 @@ def cpu_baseline(model, args):
     run(4, 1)  # warm-up (thread pool, allocator)
     v4, t4 = run(4, 5)
     vb, tb = run(args.batch, 3)
-    return {"value": vb, "unit": "timestep*mol/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"3 force evaluations of {args.batch} molecules x {args.beads} beads after a warm-up "
-                      f"(oracle/schnet_oracle.py, fp32, {tb:.1f} s)",
-            "b4": {"value": v4, "sample": f"5 force evaluations of 4 molecules x {args.beads} beads ({t4:.1f} s): "
-                                          "the size of BASELINE configs[0]"}}
+    rec = {"value": vb, "unit": "timestep*mol/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"3 force evaluations of {args.batch} molecules x {args.beads} beads after a warm-up "
+                     f"(oracle/schnet_oracle.py, fp32, {tb:.1f} s)",
+           "b4": {"value": v4, "sample": f"5 force evaluations of 4 molecules x {args.beads} beads ({t4:.1f} s): "
+                                         "the size of BASELINE configs[0]"}}
+    parity = {}
+    if engine_results:
+        # the very batch rank 0 timed (synthetic.batch's default seeds = bench.py's first_seed for rank 0)
+        pos, types, ptr, _ = synthetic.batch(args.batch, args.beads, 5.0)
+        t0 = time.perf_counter()
+        e64, f64 = so.schnet_energy_forces(so.params_to(p, torch.float64), pos.double(), types, ptr)
+        t64 = time.perf_counter() - t0
+        src = f"oracle/schnet_oracle.py in fp64 at the start positions of the timed batch ({t64:.1f} s, untimed)"
+        if "f32" in engine_results:
+            parity["f32"] = parity_record(*engine_results["f32"], e64, f64, args.batch, 1e-4, src)
+        if "w16a16" in engine_results:
+            parity["w16a16"] = parity_record(*engine_results["w16a16"], e64, f64, args.batch, 3e-3, src)
+            parity["w16a16"]["bar_note"] = ("W16A16 against fp64: the band of tests/test_model_gpu.py (the reference's own "
+                                            "W16A16 sits 9e-4 from its fp64 result; 1.1e-3 = 3 x its configuration spread is "
+                                            "the band against the reference's W16A16 vectors, held in the golden tests)")
+            t0 = time.perf_counter()
+            e16, f16 = so.schnet_energy_forces(p, pos, types, ptr, w16a16=True)
+            r16 = parity_record(*engine_results["w16a16"], e16, f16, args.batch, 3e-3,
+                                f"the oracle's W16A16 restatement (reference rounding points, fp32, "
+                                f"{time.perf_counter() - t0:.1f} s)")
+            parity["w16a16"]["against_w16a16_port"] = {k: r16[k] for k in ("energy_rel", "forces_rel",
+                                                                           "forces_rel_worst_molecule", "against")}
+    return rec, parity
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -364,6 +404,61 @@ def kernel_table(leg, dom_ms, ms_per_step):
     return raw, per_step_raw, per_step, scale
 
 
+def stored_counters(kernel, precision):
+    """The STORED rocprofv3 --pmc result of a kernel (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE / MFMA-busy passes
+    of tools/profile_round.sh, corrected as MI355X_MICROARCH.md prescribes) -- not measured in this run.  The W16A16
+    instantiations of the pair kernels have their own section."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    tj = json.load(open(tpath))
+    sec = tj if precision == "f32" else tj.get("w16a16", {})
+    rec = dict(sec.get(kernel, {}))
+    if not rec:
+        return None
+    rec["_source"] = "stored profile: profiles/pmc_traffic.json (" + str(sec.get("_source", tj.get("_source", ""))) + ")"
+    return rec
+
+
+def limiter_fields(stored, launch_ms):
+    """What the phase stamps and SQ counters say bounds the pair kernels: instruction issue -- the
+    SIMDs execute MFMA passes and VALU / LDS / memory instructions one after the other.  `bound` stays the roof `frac`
+    is priced against; these fields put the measured limiter and both pipes' utilisation beside it."""
+    out = {"limiter": "issue", "limiter_note": "per SIMD and tile the MFMA passes, VALU, transcendental, LDS and vector-"
+           "memory instructions add up to ~90 % of the tile period (profiles/*phase_stamps*, *sq_counters*): neither the "
+           "matrix pipe nor HBM is saturated"}
+    if stored:
+        out["mfma_util"] = stored.get("mfma_util")
+        if stored.get("hbm_bytes_per_launch"):
+            out["hbm_frac"] = stored["hbm_bytes_per_launch"] / (launch_ms * 1e-3) / 8.0e12
+    return out
+
+
+def graph_leg(leg, steps, batch, barrier):
+    """One hipGraph replay per timestep (noise draw, BAOAB halves, every engine launch) over the leg's simulation: ms per
+    step and the host's enqueue time per step.  The state is put back afterwards."""
+    sim = leg.sim
+    st = leg.save_state()
+    sim.capture()
+    k_g = min(max(steps, 20), 200)
+    for _ in range(k_g):
+        sim.timestep()
+    barrier()
+    tg = time.perf_counter()
+    for _ in range(k_g):
+        sim.timestep()
+    t_enq = time.perf_counter() - tg
+    barrier()
+    t_all = time.perf_counter() - tg
+    sim.check_status()
+    sim.release_graph()
+    leg.restore_state(st)
+    return {"ms_per_step": 1e3 * t_all / k_g, "value": k_g * batch / t_all, "steps": k_g,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / k_g,
+            "note": "one hipGraph replay per timestep (noise draw, BAOAB halves, every engine launch); "
+                    "bit-identical to the un-captured loop (tests/test_model_gpu.py)"}
+
+
 def smi_clock():
     """sclk / socket power as the SMI library reports them, or None (read OUTSIDE the gaps between timed regions: a
     query takes milliseconds of host time, and an idle gap of that length is itself what makes a region read slow)"""
@@ -475,12 +570,12 @@ def main():
     if args.pt and world > 1:      # one temperature per rank
         betas = beta_ladder(world)
         beta = torch.full((args.batch,), betas[rank], device=dev)
-        exchange = simulate.DistributedReplicaExchange(betas, args.batch, args.beads, seed=5)
+        exchange = simulate.DistributedReplicaExchange(betas, args.batch, args.beads, seed=5, forces=args.pt_forces)
     elif args.pt:                  # all temperatures in one batch (reference layout, beta-major)
         assert args.batch % args.pt_betas == 0
         betas = beta_ladder(args.pt_betas)
         beta = torch.tensor(betas, device=dev).repeat_interleave(args.batch // args.pt_betas)
-        exchange = simulate.LocalReplicaExchange(betas, args.batch // args.pt_betas, args.beads, seed=5)
+        exchange = simulate.LocalReplicaExchange(betas, args.batch // args.pt_betas, args.beads, seed=5, forces=args.pt_forces)
 
     drain_ev = torch.cuda.Event()
 
@@ -506,6 +601,9 @@ def main():
 
     leg = Leg(S, engine, simulate, model, args.precision, (pos, types, ptr, masses, beta), args, barrier)
     eng, sim = leg.eng, leg.sim
+    # energies and forces at the START positions (what the simulation's constructor evaluated through GradientsOut):
+    # the CPU oracle checks all of them after the timed regions (`parity`)
+    start_results = {args.precision: (sim.energy.detach().cpu().clone(), sim.f.detach().cpu().clone())}
     for _ in range(args.warmup):
         sim.timestep()
     if exchange is not None:   # untimed first attempts: RCCL sets up its point-to-point channels on first use
@@ -545,25 +643,7 @@ def main():
     # dominant kernel are recorded by the un-captured path.
     graph_info = None
     if not args.pt and world == 1 and not args.no_graph_leg:
-        st = leg.save_state()
-        sim.capture()
-        k_g = min(max(args.steps, 20), 200)
-        for _ in range(k_g):
-            sim.timestep()
-        barrier()
-        tg = time.perf_counter()
-        for _ in range(k_g):
-            sim.timestep()
-        t_enq = time.perf_counter() - tg
-        barrier()
-        t_all = time.perf_counter() - tg
-        sim.check_status()
-        sim.release_graph()
-        graph_info = {"ms_per_step": 1e3 * t_all / k_g, "value": k_g * args.batch / t_all, "steps": k_g,
-                      "host_enqueue_ms_per_step": 1e3 * t_enq / k_g,
-                      "note": "one hipGraph replay per timestep (noise draw, BAOAB halves, every engine launch); "
-                              "bit-identical to the un-captured loop (tests/test_model_gpu.py)"}
-        leg.restore_state(st)
+        graph_info = graph_leg(leg, args.steps, args.batch, barrier)
 
     pt_info = None
     if exchange is not None:
@@ -578,20 +658,26 @@ def main():
                    "accepted_per_pair": [int(m[k, k + 1]) for k in range(nb - 1)],
                    "rejected_per_pair": [int(m[k + 1, k]) for k in range(nb - 1)],
                    "accept_reject_note": "counts include the two untimed warm-up attempts",
+                   "forces": args.pt_forces + (": forces stay in their slot until the next force call, as the reference "
+                                                "(simulation/parallel_tempering.py:415-481; pinned by tests/golden/pt_run.npz)"
+                                                if args.pt_forces == "reference" else
+                                                ": forces and energies travel with the exchanged configurations"),
                    "layout": "one beta per rank, point-to-point RCCL exchange" if world > 1 else
                              f"{args.pt_betas} betas x {args.batch // args.pt_betas} replicas in one batch, in-batch HIP swap"}
         if world > 1:
             pt_info["rank0_bytes_sent_timed"] = exchange.bytes_sent - bytes_before
             pt_info["rank0_payload_transfers_total"] = exchange.payload_transfers
+            n_arr = 3 if args.pt_forces == "moved" else 2
             pt_info["bytes_per_attempt_note"] = (f"energies {4 * args.batch} B one way, accept mask {args.batch} B back; "
-                                                 f"positions+velocities+forces {3 * args.batch * args.beads * 12} B and the "
-                                                 f"energies ({4 * args.batch} B) each way only when a pair was accepted; "
-                                                 "no force evaluation in an exchange (forces travel with their configuration)")
+                                                 f"{'positions+velocities+forces' if n_arr == 3 else 'positions+velocities'} "
+                                                 f"{n_arr * args.batch * args.beads * 12} B each way only when a pair was "
+                                                 "accepted; no force evaluation in an exchange")
 
     # ---- W16A16 leg (BASELINE configs[2]) on the same batch, after the fp32 regions
     w16 = None
     if world == 1 and args.precision == "f32" and not args.pt and not args.no_w16a16_leg:
         lg = Leg(S, engine, simulate, model, "w16a16", (pos, types, ptr, masses, beta), args, barrier)
+        start_results["w16a16"] = (lg.sim.energy.detach().cpu().clone(), lg.sim.f.detach().cpu().clone())
         for _ in range(5):
             lg.sim.timestep()
         lg.profile()
@@ -602,19 +688,25 @@ def main():
         flops16 = 2.0 * (p0 + p1) * 128 * (args.num_rbf + 128)
         ach16 = flops16 / (d16 * 1e-3) / 1e12
         raw16, _, per16, sc16 = kernel_table(lg, d16, 1e3 * e16 / args.w16a16_steps)
+        st16 = stored_counters(lg.dom, "w16a16")
         w16 = {"workload": "CGSchNet 1ENH batch=128 " + PRECISIONS["w16a16"]["cfg"] + ", same batch and model",
                "value": args.w16a16_steps * args.batch / e16, "unit": "timestep*mol/s",
                "ms_per_step": 1e3 * e16 / args.w16a16_steps, "steps": args.w16a16_steps, "warmup": 5, "dtype": "f16",
                "vs_baseline": args.w16a16_steps * args.batch / e16 / PUBLISHED_BASELINE,
                "arithmetic": PRECISIONS["w16a16"]["arith"],
                "roofline": {"bound": "mfma", "kernel": lg.dom, "achieved": ach16, "peak": PEAK_F16_MFMA_TFLOPS,
-                            "unit": "TFLOP/s", "frac": ach16 / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                            "unit": "TFLOP/s", "frac": ach16 / PEAK_F16_MFMA_TFLOPS,
+                            "traffic": st16.get("hbm_bytes_per_launch") if st16 else None,
+                            "traffic_source": st16["_source"] if st16 else None,
                             "peak_note": PRECISIONS["w16a16"]["note"], "algorithmic_flops_per_launch": flops16,
-                            "avg_launch_ms": d16, "launches_per_step": lg.launches[lg.dom]},
+                            "avg_launch_ms": d16, "launches_per_step": lg.launches[lg.dom],
+                            **limiter_fields(st16, d16)},
                "timed_regions_ms_per_step": [round(v, 5) for v in m16["regions_ms"]],
                "dominant_kernel_ms_per_region": [round(v, 5) for v in m16["dom_ms"]],
                "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw16.items()},
                "kernel_ms_per_step": {n: round(v, 4) for n, v in per16.items()}}
+        if not args.no_graph_leg:   # the mode where the host's enqueue time is most of the step
+            w16["graph_replay"] = graph_leg(lg, args.w16a16_steps, args.batch, barrier)
         model._engine = eng
 
     if rank == 0:
@@ -630,11 +722,9 @@ def main():
         # HBM-side bytes per launch of the dominant kernel: a STORED rocprofv3 --pmc result (FETCH_SIZE / WRITE_SIZE
         # passes of tools/profile_round.sh, corrected as MI355X_MICROARCH.md prescribes), not measured in this run
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get(leg.dom, {}).get("hbm_bytes_per_launch")
-            traffic_src = "stored profile: profiles/pmc_traffic.json (" + str(tj.get("_source", "rocprofv3 --pmc passes")) + ")"
+        stored = stored_counters(leg.dom, args.precision)
+        if stored:
+            traffic, traffic_src = stored.get("hbm_bytes_per_launch"), stored["_source"]
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps * args.batch * world / elapsed
         raw, per_step_raw, per_step, scale = kernel_table(leg, dom_ms, ms_per_step)
@@ -666,8 +756,7 @@ def main():
                        "baseline_note": "2861 = reference README (W16A16, real 1ENH, RTX PRO 6000)"},
             "roofline": {"bound": "mfma", "kernel": leg.dom, "achieved": achieved, "peak": prec["peak"],
                          "unit": "TFLOP/s", "frac": achieved / prec["peak"],
-                         "traffic": traffic if args.precision == "f32" else None,
-                         "traffic_source": traffic_src if args.precision == "f32" else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": (None if args.precision != "f32" or args.no_filter_stash else
                                           "edge_bwd averages 507 MB per launch because two of its three launches read the "
                                           "filter stash back (482 MB each: the forward kernel's filter values, kept instead "
@@ -676,7 +765,7 @@ def main():
                                           "0.29 ms per launch"),
                          "peak_note": prec["note"],
                          "algorithmic_flops_per_launch": alg_flops, "avg_launch_ms": dom_ms,
-                         "launches_per_step": leg.launches[leg.dom]},
+                         "launches_per_step": leg.launches[leg.dom], **limiter_fields(stored, dom_ms)},
             "timed_regions_ms_per_step": [round(v, 5) for v in regions_ms],
             "dominant_kernel_ms_per_region": [round(v, 5) for v in dom_regions],
             "smi": meas["smi"],
@@ -706,7 +795,11 @@ def main():
         if w16 is not None:
             line["w16a16"] = w16
         if world == 1 and not args.no_cpu_baseline and not args.pt:
-            line["cpu_baseline"] = cpu_baseline(model, args)
+            line["cpu_baseline"], parity = cpu_baseline(model, args, start_results)
+            if args.precision in parity:
+                line["parity"] = parity[args.precision]
+            if w16 is not None and "w16a16" in parity:
+                w16["parity"] = parity["w16a16"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -99,10 +99,6 @@ struct EdgeArgs {
   // does not recompute layer 1.  Tile t of molecule m: WST_TILE_FLOATS floats at (m * cap / 32 + t) * WST_TILE_FLOATS,
   // record [feature slice 0..3][register group q 0..3][lane 0..63] x 16 bytes = registers 4q .. 4q+3 of that lane.
   float* wst;
-  // tabulated-filter mode (fmd_engine_tab.hip): this block's table, [tab_k intervals][128 features] x 16 B
-  const float* tab;
-  int tab_k;
-  float tab_inv_h;
 #ifdef FMD_PHASE_STAMPS
   unsigned long long* stamps;  // diagnostic build (make stamps) only: [workgroup][8 waves][FMD_NSTAMP] cycle totals
   int dbg;                     // diagnostic build only: bit 0 = consumers skip their A-B work, bit 1 = producers skip staging
@@ -201,8 +197,6 @@ struct FinishArgs {
 int setup_pairs_attrs();
 int setup_edge_fwd_attrs();
 int setup_edge_bwd_attrs();
-int setup_tab_attrs();
-int launch_tab_fwd(const EdgeArgs& a, int64_t n_mol, hipStream_t s);
 int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s);
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s);
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s);

@@ -53,6 +53,7 @@ __device__ __forceinline__ f16x8 gw_frag(gw_lds_ptr a1, gw_lds_ptr a2) {
 // fp32-grade kernel as well.
 template <int NS0, bool NEED_GX1, bool FIRST, bool SHARE, bool HALF, bool FS, bool STASH>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
+  static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       for (int s = 0; s < NS0; ++s) {
         a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
         if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
-        if (SHARE && !HALF) {
+        if constexpr (SHARE && !HALF) {
           ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[(w * 4 + s) * 64 + lane];
           acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
         }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
         nx.gd = gd_n;
         fetch(t_fetch);
         f32x16 z1 = zero16(), p1 = zero16();
-        if (SHARE) {
+        if constexpr (SHARE) {
           // shared fragments: p accumulates Gc = Wc raw.  The fragments of k-step s+1 are requested before the MFMAs
           // of k-step s (an LDS round trip per k-step would otherwise sit in front of every group of MFMAs).
           const float* fbuf = frag_cur;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
             constexpr int s = decltype(sc)::value;
             f16x8 nh = bh, nl = bl;
             if constexpr (s + 1 < NS0) { nh = frag_rd(s + 1, 0); nl = frag_rd(s + 1, 1); }
-            if (HALF) {  // W16A16: the second record holds f16(raw (d - centre)); no cancellation-prone Wc form
+            if constexpr (HALF) {  // W16A16: the second record holds f16(raw (d - centre)); no cancellation-prone Wc form
               z1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bh, z1, 0, 0, 0);
               p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[s], bl, p1, 0, 0, 0);
             } else {
@@ -685,16 +686,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
 
 namespace fmd_eng {
 
-// (NEED_GX1, FIRST, SHARE, HALF, FS, STASH); the stash form only exists with a gx1 aggregate
-#define FMD_BWD_5(M_, ST_)                                                                      \
+// (NEED_GX1, FIRST, SHARE, HALF, FS, STASH); the stash form only exists with a gx1 aggregate and in fp32-grade
+// precision (carve_ws allocates no stash for W16A16: ADVICE r4 -- those instantiations could never be launched)
+#define FMD_BWD_F32(M_, ST_)                                                                    \
   M_(true, true, false, false, false, ST_) M_(true, false, false, false, false, ST_)           \
-  M_(true, true, false, true, false, ST_) M_(true, false, false, true, false, ST_)             \
   M_(true, true, true, false, false, ST_) M_(true, false, true, false, false, ST_)             \
-  M_(true, true, true, true, false, ST_) M_(true, false, true, true, false, ST_)               \
-  M_(true, true, true, false, true, ST_) M_(true, false, true, false, true, ST_)               \
-  M_(true, true, true, true, true, ST_) M_(true, false, true, true, true, ST_)
+  M_(true, true, true, false, true, ST_) M_(true, false, true, false, true, ST_)
+#define FMD_BWD_HALF(M_)                                                                        \
+  M_(true, true, false, true, false, false) M_(true, false, false, true, false, false)         \
+  M_(true, true, true, true, false, false) M_(true, false, true, true, false, false)           \
+  M_(true, true, true, true, true, false) M_(true, false, true, true, true, false)
 #define FMD_BWD_ALL(M_)                                                                         \
-  FMD_BWD_5(M_, false) FMD_BWD_5(M_, true)                                                      \
+  FMD_BWD_F32(M_, false) FMD_BWD_F32(M_, true) FMD_BWD_HALF(M_)                                 \
   M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
   M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
   M_(false, true, true, false, false, false) M_(false, false, true, false, false, false)       \
@@ -728,7 +731,7 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
                              : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag +
                                    (a.fs ? 0 : frag + (size_t)(4096 + 128) * sizeof(float));
   const bool share = lds_sh <= MAX_LDS_BYTES;
-  const bool stash = need && a.wst != nullptr;
+  const bool stash = need && !half && a.wst != nullptr;
   if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
 #define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                  \
   if (need == N_ && first == F_ && (share || a.fs) == S_ && half == H_ && a.fs == FS_ && stash == ST_) {  \

@@ -35,6 +35,7 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 // kernel of the same block, which then neither recomputes layer 1 nor needs the hidden tile.
 template <int NS0, bool HALF, bool FS, bool SH, bool STASH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
+  static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
@@ -491,9 +492,9 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 
 namespace fmd_eng {
 
-#define FMD_FWD_ALL(M_)                                                                            \
-  M_(false, false, false) M_(true, false, false) M_(false, true, false) M_(true, true, false) M_(false, false, true) \
-  M_(true, false, true)
+// (HALF, FS, SH); the stash variants exist in fp32-grade precision only (no stash is ever allocated for W16A16)
+#define FMD_FWD_F32(M_) M_(false, false, false) M_(false, true, false) M_(false, false, true)
+#define FMD_FWD_HALF(M_) M_(true, false, false) M_(true, true, false) M_(true, false, true)
 
 template <int NS0, bool STASH>
 static int set_fwd_attrs() {
@@ -501,7 +502,8 @@ static int set_fwd_attrs() {
   if (hipFuncSetAttribute((const void*)edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH>,                        \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)       \
     return FMD_ELAUNCH;
-  FMD_FWD_ALL(FMD_ONE)
+  FMD_FWD_F32(FMD_ONE)
+  if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
 #undef FMD_ONE
   return FMD_OK;
 }
@@ -527,14 +529,15 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
     edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH><<<grid, 512, (SH_) ? lds_sh : lds, s>>>(a);  \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                \
   }
-  FMD_FWD_ALL(FMD_ONE)
+  FMD_FWD_F32(FMD_ONE)
+  if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
 #undef FMD_ONE
   return FMD_EUNSUPPORTED;
 }
 
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
-  if (a.wst) return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s) : launch_fwd<4, true>(a, half, grid, s);
+  if (a.wst && !half) return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s) : launch_fwd<4, true>(a, half, grid, s);
   return num_rbf <= 32 ? launch_fwd<2, false>(a, half, grid, s) : launch_fwd<4, false>(a, half, grid, s);
 }
 

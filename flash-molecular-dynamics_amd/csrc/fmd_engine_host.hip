@@ -4,6 +4,7 @@
 // has zero-padded to the kernels' width, hidden = filters = 128.  The kernels live in
 // fmd_engine_{pairs,edge_fwd,edge_bwd,node}.hip.
 #include <atomic>
+#include <cmath>
 #include <vector>
 
 #include "fmd_engine.h"
@@ -20,21 +21,7 @@ struct BlockOff {
 };
 struct PackLayout {
   int64_t emb, centers, blocks, block_stride, outs, out_stride, emb_x1, total;
-  // FMD_FLAG_TABULATED_FILTER: per block [tab_k intervals][128 features] x 16 B, the cubic of W(d) on interval k
-  int64_t tab, tab_stride;
-  int tab_k;
-  float tab_inv_h;
 };
-// grid spacing of the filter table: the power of two that gives 1024..2047 intervals over [0, cutoff] -- with h = 2^e
-// both k = floor(d / h) and t = d / h - k are EXACT in fp32 (any other h puts the rounding error of 1 / h, times k, into t)
-void tab_grid(float cutoff, int& k, float& inv_h) {
-  int e = 0;
-  while (ldexpf(1.0f, e) * 1024.0f > cutoff) --e;       // largest h = 2^e with cutoff / h >= 1024
-  while (ldexpf(1.0f, e + 1) * 1024.0f <= cutoff) ++e;
-  const float h = ldexpf(1.0f, e);
-  inv_h = ldexpf(1.0f, -e);
-  k = (int)ceilf(cutoff / h);
-}
 constexpr int64_t BLOCK_FLOATS = 3 * F + 6 * (int64_t)SLICE + 4 * Q0_FLOATS + 4 * Q1_FLOATS;
 constexpr int64_t OUT_FLOATS = 2 * (int64_t)SLICE + F;
 
@@ -48,12 +35,6 @@ PackLayout pack_layout(const fmd_schnet_desc* d) {
   L.out_stride = OUT_FLOATS;
   L.emb_x1 = L.outs + (int64_t)d->num_out * OUT_FLOATS;  // [embedding_size][128]: embedding lin1(block 0)^T
   L.total = L.emb_x1 + (int64_t)d->embedding_size * F;
-  L.tab = L.total; L.tab_stride = 0; L.tab_k = 0; L.tab_inv_h = 0.f;
-  if (d->flags & FMD_FLAG_TABULATED_FILTER) {
-    tab_grid(d->cutoff, L.tab_k, L.tab_inv_h);
-    L.tab_stride = (int64_t)L.tab_k * F * 4;
-    L.total = L.tab + (int64_t)d->num_blocks * L.tab_stride;
-  }
   return L;
 }
 BlockOff block_off(const PackLayout& L, int l) {
@@ -198,7 +179,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   // aggregate to update (all but the first).  Last in the carve: nothing else moves when it is switched off.
   // fp32-grade precision only: with a third of the MFMA work the W16A16 kernels gain less from the dropped layer than the
   // stash traffic costs them (same-box A/B: 108.2k against 110.5k timestep*mol/s).
-  const bool stash = d->precision == FMD_PREC_F32 && !(d->flags & (FMD_FLAG_NO_FILTER_STASH | FMD_FLAG_TABULATED_FILTER));
+  const bool stash = d->precision == FMD_PREC_F32 && !(d->flags & FMD_FLAG_NO_FILTER_STASH);
   for (int l = 0; l < d->num_blocks; ++l)
     w.wst[l] = (l > 0 && stash) ? (float*)take(n_mol * cap * F * (int64_t)sizeof(float)) : nullptr;
   w.total = p - reinterpret_cast<char*>(base);
@@ -215,8 +196,10 @@ bool desc_ok(const fmd_schnet_desc* d) {
   if (d->out_width[d->num_out - 1] != 1) return false;
   if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_W16A16) return false;
   if (d->embedding_size < 1) return false;
-  if (d->flags & ~(FMD_FLAG_NO_FILTER_STASH | FMD_FLAG_TABULATED_FILTER)) return false;
-  if ((d->flags & FMD_FLAG_TABULATED_FILTER) && d->precision != FMD_PREC_F32) return false;
+  if (d->flags & ~FMD_FLAG_NO_FILTER_STASH) return false;
+  // the struct arrives from C callers: a cutoff or gamma that is not a finite positive / finite number must not reach
+  // the kernels
+  if (!(d->cutoff > 0.f) || !std::isfinite(d->cutoff) || !std::isfinite(d->gamma)) return false;
   return true;
 }
 
@@ -230,7 +213,6 @@ int ensure_kernel_attrs() {
   int rc = setup_pairs_attrs();
   if (rc == FMD_OK) rc = setup_edge_fwd_attrs();
   if (rc == FMD_OK) rc = setup_edge_bwd_attrs();
-  if (rc == FMD_OK) rc = setup_tab_attrs();
   if (rc == FMD_OK) done[dev].store(1, std::memory_order_release);
   return rc;
 }
@@ -251,61 +233,6 @@ extern "C" int fmd_debug_set_stamps(void* device_buffer, int block, int fwd, int
   return FMD_OK;
 }
 #endif
-
-namespace {
-// W_f(d) = C(d) sum_u W1[f][u] tanh(sum_j W0[u][j] rbf_j(d) + b0[u]),  rbf_j(d) = exp(gamma (d - c_j)^2) C(d), and
-// dW_f/dd, in fp64 (reference models/schnet.py:710-713, mlp.py:41-48, radial_basis/gaussian.py:98-101, cutoff.py:137-145)
-void filter_value_slope(const fmd_schnet_desc* d, const fmd_schnet_block_weights& b, const float* centers, double x,
-                        double* val, double* slope) {
-  const int R = d->num_rbf;
-  const double rc = d->cutoff, g = d->gamma, pi = 3.14159265358979323846;
-  const bool in = x < rc;
-  const double C = in ? 0.5 * (cos(pi * x / rc) + 1.0) : 0.0, dC = in ? -0.5 * (pi / rc) * sin(pi * x / rc) : 0.0;
-  std::vector<double> rbf(R), drbf(R), h(F), dh(F);
-  for (int j = 0; j < R; ++j) {
-    const double u = x - centers[j], ex = exp(g * u * u);
-    rbf[j] = ex * C;
-    drbf[j] = ex * (2.0 * g * u * C + dC);
-  }
-  for (int u = 0; u < F; ++u) {
-    double z = b.f0_b[u], dz = 0.0;
-    for (int j = 0; j < R; ++j) {
-      z += (double)b.f0_w[(size_t)u * R + j] * rbf[j];
-      dz += (double)b.f0_w[(size_t)u * R + j] * drbf[j];
-    }
-    h[u] = tanh(z);
-    dh[u] = (1.0 - h[u] * h[u]) * dz;
-  }
-  for (int f = 0; f < F; ++f) {
-    double v = 0.0, dv = 0.0;
-    for (int u = 0; u < F; ++u) {
-      v += (double)b.f1_w[(size_t)f * F + u] * h[u];
-      dv += (double)b.f1_w[(size_t)f * F + u] * dh[u];
-    }
-    val[f] = v * C;
-    slope[f] = dv * C + v * dC;
-  }
-}
-// one cubic per interval and feature from the Hermite data of its two knots: with t = (d - d_k) / h,
-// W = a0 + t (a1 + t (a2 + t a3)),  a0 = f0, a1 = h m0, a2 = 3 (f1 - f0) - h (2 m0 + m1), a3 = 2 (f0 - f1) + h (m0 + m1)
-void build_filter_table(const fmd_schnet_desc* d, const fmd_schnet_block_weights& b, const float* centers, int K,
-                        double h, float* out) {
-  std::vector<double> v0(F), m0(F), v1(F), m1(F);
-  filter_value_slope(d, b, centers, 0.0, v0.data(), m0.data());
-  for (int k = 0; k < K; ++k) {
-    filter_value_slope(d, b, centers, (k + 1) * h, v1.data(), m1.data());
-    for (int f = 0; f < F; ++f) {
-      float* r = out + ((int64_t)k * F + f) * 4;
-      r[0] = (float)v0[f];
-      r[1] = (float)(h * m0[f]);
-      r[2] = (float)(3.0 * (v1[f] - v0[f]) - h * (2.0 * m0[f] + m1[f]));
-      r[3] = (float)(2.0 * (v0[f] - v1[f]) + h * (m0[f] + m1[f]));
-    }
-    v0.swap(v1);
-    m0.swap(m1);
-  }
-}
-}  // namespace
 
 extern "C" int64_t fmd_schnet_pack_bytes(const fmd_schnet_desc* desc) {
   if (!desc_ok(desc)) return FMD_EINVAL;
@@ -360,8 +287,6 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     }
     pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false, 1.0f);
     pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);
-    if (L.tab_k > 0)
-      build_filter_table(desc, b, centers, L.tab_k, 1.0 / (double)L.tab_inv_h, out + L.tab + l * L.tab_stride);
   }
   int in_w = F;
   for (int k = 0; k < desc->num_out; ++k) {
@@ -411,12 +336,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
   if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
   const int cus = device_cus();
-  // tabulated-filter mode (prototype scope): forward pair kernel only, whole-aggregate molecules, two feature halves
-  const bool tab = (desc->flags & FMD_FLAG_TABULATED_FILTER) != 0;
-  if (tab && (fs || (size_t)2 * max_beads_per_mol * 72 * sizeof(float) > MAX_LDS_BYTES)) return FMD_EUNSUPPORTED;
-  const int split = (fs || tab) ? 2 : resolve_split(desc, n_mol, cus);  // FS: the two feature halves
+  const int split = fs ? 2 : resolve_split(desc, n_mol, cus);  // FS: the two feature halves
   // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
-  const bool chain = !fs && !tab && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
+  const bool chain = !fs && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
   const int n_slabs = chain ? 2 : split;                       // regular slabs the node kernels add
   const int64_t pair_wgs = chain ? cus : n_mol;                // grid.y of the pair kernels
   if ((int64_t)(n_slabs + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
@@ -440,7 +362,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     // the pair kernels' work items (sched_body in fmd_engine_pairs.hip): balanced when the split is left to the library
     // and the whole launch is one round of workgroups; a caller-given n_split keeps the static tile interleave
     sa.npairs = ws.npairs; sa.mol_ptr = mol_ptr; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
-    sa.balanced = chain ? 2 : (!fs && !tab && n_mol >= 2 && n_mol <= 256 && n_mol * split <= cus && desc->n_split == 0) ? 1 : 0;
+    sa.balanced = chain ? 2 : (!fs && n_mol >= 2 && n_mol <= 256 && n_mol * split <= cus && desc->n_split == 0) ? 1 : 0;
     sa.n_wg = (int)pair_wgs;
     sa.n_nodes = n_nodes; sa.items = ws.items; sa.extra_row = ws.extra_row;
     ev_begin();
@@ -469,8 +391,6 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
     ea.wst = ws.wst[l];
-    ea.tab = tab ? pk + PL.tab + l * PL.tab_stride : nullptr; ea.tab_k = PL.tab_k; ea.tab_inv_h = PL.tab_inv_h;
-    if (fwd && tab) return launch_tab_fwd(ea, n_mol, s);
 #ifdef FMD_PHASE_STAMPS
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
     ea.dbg = (ea.stamps || g_stamp_block == -2) ? g_stamp_dbg : 0;   // block -2: the switches apply to every launch

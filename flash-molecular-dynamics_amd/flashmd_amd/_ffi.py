@@ -63,8 +63,7 @@ class SchnetDesc(ctypes.Structure):
 
 
 FLAG_NO_FILTER_STASH = 1   # FMD_FLAG_NO_FILTER_STASH
-FLAG_TABULATED_FILTER = 2  # FMD_FLAG_TABULATED_FILTER
-ABI_VERSION = 4            # what this binding (and engine.py's handling of the status words) was written for
+ABI_VERSION = 5            # what this binding (and engine.py's handling of the status words) was written for
 
 
 class SchnetBlockWeights(ctypes.Structure):

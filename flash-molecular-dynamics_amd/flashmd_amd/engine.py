@@ -82,14 +82,11 @@ def _output_weights(on):
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True,
-                 tabulated_filter: bool = False):
+    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True):
         """``precision``: "f32" (default) or "w16a16"; a model whose filter and output networks
         were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself.  ``filter_stash=False``: the
         backward pair kernels recompute filter layer 1 instead of reading the values the forward kernels kept
-        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits).  ``tabulated_filter=True`` (opt-in, fp32
-        only): the filter network of every block is tabulated over the pair distance when the weights are packed and
-        the pair kernels interpolate it (FMD_FLAG_TABULATED_FILTER) instead of evaluating it on the MFMA."""
+        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits)."""
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -141,7 +138,7 @@ class FusedSchNetEngine:
             raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
         d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
-        d.flags = (0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH) | (_ffi.FLAG_TABULATED_FILTER if tabulated_filter else 0)
+        d.flags = 0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH
         self._flags = d.flags   # as requested; _workspace() may add FMD_FLAG_NO_FILTER_STASH for a very large batch
         self.desc = d
 
@@ -201,15 +198,28 @@ class FusedSchNetEngine:
         if self._ws_key != key:
             # the filter stash is sized for the worst-case pair list (n_mol * cap * 512 bytes per block but the first):
             # batches for which that would be unreasonable fall back to recomputation in the backward pass
+            # (a fixed ceiling, and never more than half of what the device has free right now, the current workspace --
+            # about to be released -- counted as free; an allocation that fails all the same is retried once without)
             self.desc.flags = self._flags
+            self._ws = None
+            wants_stash = self.desc.precision == PRECISIONS["f32"] and not (self._flags & _ffi.FLAG_NO_FILTER_STASH)
             stash = (self.desc.num_blocks - 1) * n_mol * cap * 512
-            if self.desc.precision == PRECISIONS["f32"] and not (self._flags & _ffi.FLAG_NO_FILTER_STASH) \
-                    and stash > MAX_STASH_BYTES:
+            if wants_stash and stash > min(MAX_STASH_BYTES, torch.cuda.mem_get_info(self.device)[0] // 2):
                 self.desc.flags = self._flags | _ffi.FLAG_NO_FILTER_STASH
-            nbytes = _ffi.lib().fmd_schnet_workspace_bytes(ctypes.byref(self.desc), n_mol, n_nodes, cap)
-            if nbytes <= 0:
-                raise RuntimeError("fmd_schnet_workspace_bytes failed")
-            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+
+            def alloc():
+                nbytes = _ffi.lib().fmd_schnet_workspace_bytes(ctypes.byref(self.desc), n_mol, n_nodes, cap)
+                if nbytes <= 0:
+                    raise RuntimeError("fmd_schnet_workspace_bytes failed")
+                return torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+
+            try:
+                self._ws = alloc()
+            except torch.cuda.OutOfMemoryError:
+                if not wants_stash or (self.desc.flags & _ffi.FLAG_NO_FILTER_STASH):
+                    raise
+                self.desc.flags = self._flags | _ffi.FLAG_NO_FILTER_STASH
+                self._ws = alloc()
             self._ws_key = key
         off = (-self._ws.data_ptr()) % 256
         return ctypes.c_void_p(self._ws.data_ptr() + off)

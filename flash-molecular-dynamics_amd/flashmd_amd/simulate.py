@@ -415,33 +415,80 @@ def pt_count(matrix: torch.Tensor, a: int, b: int, approved: int, n_indep: int):
     matrix[b, a] += n_indep - approved
 
 
-def pt_accept(u_a, u_b, beta_a: float, beta_b: float, rand_u):
-    """Metropolis criterion of reference parallel_tempering.py:393-394:
-    accept where rand < exp((U_a - U_b) (beta_a - beta_b))."""
-    return rand_u < torch.exp((u_a - u_b) * (beta_a - beta_b))
+def pt_probability(u_a, u_b, beta_a, beta_b):
+    """exp((U_a - U_b) (beta_a - beta_b)), every operand in the energies' dtype as the reference forms it from its
+    fp32 ``self.beta`` tensor (parallel_tempering.py:385-393); ``beta_*``: floats or tensors."""
+    ba = torch.as_tensor(beta_a, dtype=u_a.dtype, device=u_a.device)
+    bb = torch.as_tensor(beta_b, dtype=u_a.dtype, device=u_a.device)
+    return torch.exp((u_a - u_b) * (ba - bb))
+
+
+def pt_accept(u_a, u_b, beta_a, beta_b, rand_u):
+    """Metropolis criterion of reference parallel_tempering.py:393-394: accept where rand < p."""
+    return rand_u < pt_probability(u_a, u_b, beta_a, beta_b)
+
+
+def pt_vscale(beta_new: float, beta_old: float, dtype=torch.float32):
+    """sqrt(beta_new_slot / beta_of_the_slot_the_velocities_come_from) formed in fp32 like the reference's
+    ``torch.sqrt(betas_a / betas_b)`` (parallel_tempering.py:467-470)"""
+    return torch.sqrt(torch.tensor(beta_new, dtype=dtype) / torch.tensor(beta_old, dtype=dtype))
+
+
+FORCE_MODES = ("reference", "moved")
+
+
+def _check_force_mode(forces: str) -> str:
+    if forces not in FORCE_MODES:
+        raise ValueError(f"forces must be one of {FORCE_MODES}, got {forces!r}")
+    return forces
+
+
+class _UniformSource:
+    """Where an exchange attempt's uniform numbers come from.  The reference draws ``torch.rand(n)`` -- n = all pairs of
+    the attempt, pair-major -- from the GLOBAL CPU generator (parallel_tempering.py:394): ``seed=None`` does exactly
+    that; an integer seed uses a private CPU generator; ``rand_source(attempt, n) -> Tensor[n]`` injects the numbers
+    (the parity tests replay the reference's own draws through it)."""
+
+    def __init__(self, seed, rand_source):
+        self.rand_source = rand_source
+        self.gen = None if (seed is None or rand_source is not None) else torch.Generator().manual_seed(seed)
+
+    def draw(self, attempt: int, n: int):
+        if self.rand_source is not None:
+            u = torch.as_tensor(self.rand_source(attempt, n), dtype=torch.float32).cpu()
+            assert u.shape == (n,), (u.shape, n)
+            return u
+        return torch.rand(n) if self.gen is None else torch.rand(n, generator=self.gen)
 
 
 class DistributedReplicaExchange:
     """Parallel tempering with ONE temperature per rank (BASELINE config 5): rank r simulates
     ``n_indep`` replicas at betas[r]; every ``interval`` steps neighbouring ranks attempt to swap
     replica k of one with replica k of the other (reference simulation/parallel_tempering.py:368-481,
-    where all temperatures live in one batch).
+    where all temperatures live in one batch: rank r = the reference's slot block r of its beta-major layout).
 
     The force path never communicates.  An exchange attempt is point-to-point between the two
     partner ranks only (torch.distributed send/recv = RCCL over the direct xGMI link on GPUs, gloo
     on CPU).  The Metropolis decision has ONE source, the lower rank of the pair: the upper rank sends
-    its energies (n_indep floats), the lower rank draws the uniform numbers (a CPU generator keyed by
-    (seed, attempt, lower rank); the reference draws from the global CPU RNG, parallel_tempering.py:394),
-    decides, and sends the accept mask back (n_indep bytes) -- two ranks can never disagree on a
-    borderline ``rand < p`` and then wait for a transfer the other never posts.  Positions, velocities AND
-    forces of the batch (fixed size, <= 1.24 MB at 128 x 269 beads, plus the energies) cross the link, once each
-    way, only when at least one pair was accepted, and are applied where the mask says so.  The forces travel with
-    the configuration they were computed for: F(x) depends on the replica's own coordinates only (one model for all
-    temperatures), so nothing is re-evaluated after an exchange -- the reference keeps the pre-exchange forces until
-    the next timestep's force call (parallel_tempering.py:415-481), which gives the exchanged replicas one half-kick
-    with the other configuration's forces; moving the forces costs 0.4 MB per way and none of that."""
+    its energies (n_indep floats), the lower rank draws the uniform numbers, decides, and sends the accept mask back
+    (n_indep bytes) -- two ranks can never disagree on a borderline ``rand < p`` and then wait for a transfer the other
+    never posts.  Uniform numbers: a CPU generator keyed by (seed, attempt, lower rank), or -- ``rand_source(attempt, n)``
+    -- the attempt's whole pair-major vector as the reference draws it (parallel_tempering.py:394), of which the lower
+    rank of the j-th proposed pair takes entries [j n_indep, (j+1) n_indep).
 
-    def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0, group=None):
+    ``forces`` selects what happens to forces and energies of an accepted pair:
+      "reference" (default)  as parallel_tempering.py:415-481: positions and rescaled velocities cross, ``sim.f`` and
+                  ``sim.energy`` stay where they are -- the next timestep's first half-kick uses the forces of the
+                  configuration that LEFT the slot (simulation/base.py:612-615 -> langevin.py:137), exactly the
+                  reference's trajectory (tests/test_parallel_tempering_reference.py replays its PTSimulation run);
+      "moved"     forces and energies travel with the configuration they were computed for (F(x) depends on the
+                  replica's own coordinates only, one model for all temperatures), so the half-kick after an exchange
+                  uses the forces AT the new positions, still without a force evaluation; 0.4 MB more per way.
+    Payload (fixed size, <= 0.83 / 1.24 MB at 128 x 269 beads) crosses the link once each way, only when at least one
+    pair was accepted, and is applied where the mask says so."""
+
+    def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0, group=None, forces: str = "reference",
+                 rand_source=None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -449,13 +496,16 @@ class DistributedReplicaExchange:
         assert len(betas) == self.world, "one beta per rank"
         self.betas = [float(b) for b in betas]
         self.n_indep, self.n_atoms, self.seed = n_indep, n_atoms, seed
+        self.forces = _check_force_mode(forces)
+        self.rand_source = rand_source
         self.attempt = 0
         # this rank's share of the acceptance matrix: the lower rank of a pair counts for the pair
         self.local_matrix = torch.zeros(self.world, self.world, dtype=torch.int64)
         self.exchange_seconds = 0.0   # wall time spent inside exchange attempts that had a partner
         self.exchanges = 0
-        self.bytes_sent = 0           # payload bytes this rank put on the link (energies / mask / x+v)
+        self.bytes_sent = 0           # payload bytes this rank put on the link (energies / mask / x+v[+f])
         self.payload_transfers = 0    # attempts in which positions+velocities crossed
+        self.last_accept = None       # accept mask of this rank's pair in the last attempt (None: sat out)
         # gloo moves host memory: device tensors are staged through the CPU (tests, rehearsals); RCCL takes them as they are
         self._stage = dist.get_backend(group) != "nccl"
 
@@ -487,6 +537,15 @@ class DistributedReplicaExchange:
             req.wait()
         return inc.to(t.device)
 
+    def _uniforms(self, attempt: int, even: bool, lo: int):
+        if self.rand_source is None:
+            g = torch.Generator().manual_seed((self.seed * 1000003 + attempt) * 4099 + lo)
+            return torch.rand(self.n_indep, generator=g)
+        pairs = pt_pairs(self.world, even)
+        j = [a for a, _ in pairs].index(lo)
+        u = torch.as_tensor(self.rand_source(attempt, len(pairs) * self.n_indep), dtype=torch.float32).cpu()
+        return u[j * self.n_indep:(j + 1) * self.n_indep]
+
     def __call__(self, sim: "LangevinSimulation"):
         import time
 
@@ -494,6 +553,7 @@ class DistributedReplicaExchange:
         peer = self.partner(even)
         attempt = self.attempt
         self.attempt += 1
+        self.last_accept = None
         if peer is None:      # an end rank sits this phase out (odd phase: ranks 0 and W-1 for even W)
             return
         t0 = time.perf_counter()
@@ -505,29 +565,31 @@ class DistributedReplicaExchange:
             acc = self._recv(torch.empty(self.n_indep, dtype=torch.uint8, device=u_mine.device), lo).bool()
         else:
             u_peer = self._recv(u_mine, hi)
-            g = torch.Generator().manual_seed((self.seed * 1000003 + attempt) * 4099 + lo)
-            rand_u = torch.rand(self.n_indep, generator=g).to(u_mine.device)
+            rand_u = self._uniforms(attempt, even, lo).to(u_mine.device)
             acc = pt_accept(u_mine, u_peer, self.betas[lo], self.betas[hi], rand_u)
             self._send(acc.to(torch.uint8), hi)
+        self.last_accept = acc
         n_acc = int(acc.sum())   # one host sync per attempt; the same mask on both partners by construction
         if self.rank == lo:
             pt_count(self.local_matrix, lo, hi, n_acc, self.n_indep)
         if n_acc:
-            # 3. positions, velocities and forces of the whole batch (and the energies) cross the link once, each way
-            incoming = self._swap(torch.stack([sim.x, sim.v, sim.f]).contiguous(), peer)
-            u_peer_all = self._swap(u_mine, peer)
+            # 3. positions and velocities (and, "moved", forces and energies) of the whole batch cross the link once,
+            #    each way
+            moved = self.forces == "moved"
+            parts = [sim.x, sim.v, sim.f] if moved else [sim.x, sim.v]
+            incoming = self._swap(torch.stack(parts).contiguous(), peer)
             self.payload_transfers += 1
             # 4. apply where accepted; velocities rescaled as reference parallel_tempering.py:467-477
             #    (slot a receives v_b * sqrt(beta_a / beta_b), slot b receives v_a * sqrt(beta_b / beta_a))
             mask = acc.repeat_interleave(self.n_atoms)[:, None]
-            scale = math.sqrt(self.betas[self.rank] / self.betas[peer])
+            scale = pt_vscale(self.betas[self.rank], self.betas[peer], sim.v.dtype).to(sim.v.device)
             # (in place: a captured hipGraph keeps reading and writing these buffers)
             sim.x.copy_(torch.where(mask, incoming[0], sim.x))
             sim.v.copy_(torch.where(mask, incoming[1] * scale, sim.v))
-            # forces and energies belong to the coordinates they were computed for and move with them: the next B
-            # half-kick uses the forces AT the new positions without a force evaluation
-            sim.f.copy_(torch.where(mask, incoming[2], sim.f))
-            sim.energy.copy_(torch.where(acc, u_peer_all, sim.energy))
+            if moved:
+                u_peer_all = self._swap(u_mine, peer)
+                sim.f.copy_(torch.where(mask, incoming[2], sim.f))
+                sim.energy.copy_(torch.where(acc, u_peer_all, sim.energy))
         self.exchange_seconds += time.perf_counter() - t0
         self.exchanges += 1
 
@@ -536,7 +598,7 @@ class DistributedReplicaExchange:
         ranks; a collective, for export time only (reference parallel_tempering.py:504-517 writes it to
         ``{filename}_acceptance_XXXX.npy`` and resets it)."""
         dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
-        m = self.local_matrix.to(dev)
+        m = self.local_matrix.to(dev).clone()   # (a copy: all_reduce works in place, this rank's counts must survive it)
         self.dist.all_reduce(m, group=self.group)
         return m.cpu()
 
@@ -554,17 +616,32 @@ class DistributedReplicaExchange:
 class LocalReplicaExchange:
     """All temperatures in one batch on one GPU (the reference's layout: beta-major blocks of
     ``n_indep`` replicas, parallel_tempering.py:204-220); accepted pairs are swapped in place by the
-    HIP kernel behind fmd_pt_swap_local."""
+    HIP kernel behind fmd_pt_swap_local (with every MLCG_USE_* gate off -- ``sim.use_hip`` False -- by the same torch
+    indexing the reference uses, which is what runs on the CPU).
 
-    def __init__(self, betas, n_indep: int, n_atoms: int, seed: int = 0):
+    ``seed=None`` draws the uniform numbers from the global CPU generator as the reference does
+    (parallel_tempering.py:394), an integer from a private one, ``rand_source(attempt, n)`` injects them.
+    ``forces``: "reference" (default) leaves ``sim.f`` / ``sim.energy`` in place as parallel_tempering.py:415-481 does;
+    "moved" swaps them with the configurations (see DistributedReplicaExchange).  ``last`` keeps the last attempt's
+    proposal and decision (pairs, probabilities, uniforms, mask) for bookkeeping and tests."""
+
+    def __init__(self, betas, n_indep: int, n_atoms: int, seed: Optional[int] = 0, forces: str = "reference",
+                 rand_source=None):
         self.betas, self.n_indep, self.n_atoms = [float(b) for b in betas], n_indep, n_atoms
-        self.gen = torch.Generator().manual_seed(seed)
+        self.forces = _check_force_mode(forces)
+        self.uniforms = _UniformSource(seed, rand_source)
         self.attempt = 0
         self.acceptance_matrix = torch.zeros(len(self.betas), len(self.betas), dtype=torch.int64)
+        self.last = None
         self._scratch = None
+
+    def reset_acceptance(self):
+        """what the reference does after writing ``{filename}_acceptance_XXXX.npy`` (parallel_tempering.py:514-517)"""
+        self.acceptance_matrix.zero_()
 
     def __call__(self, sim: "LangevinSimulation"):
         even = self.attempt % 2 == 0
+        attempt = self.attempt
         self.attempt += 1
         pairs = pt_pairs(len(self.betas), even)
         if not pairs:
@@ -574,19 +651,39 @@ class LocalReplicaExchange:
         mol_a = torch.cat([a * self.n_indep + k for a, _ in pairs]).to(dev)
         mol_b = torch.cat([b * self.n_indep + k for _, b in pairs]).to(dev)
         beta = sim.beta_mol
-        p = torch.exp((sim.energy[mol_a] - sim.energy[mol_b]) * (beta[mol_a] - beta[mol_b]))
-        acc = (torch.rand(p.numel(), generator=self.gen).to(dev) < p).to(torch.uint8)
+        p = pt_probability(sim.energy[mol_a], sim.energy[mol_b], beta[mol_a], beta[mol_b])
+        u = self.uniforms.draw(attempt, p.numel())
+        acc = (u.to(dev) < p).to(torch.uint8)
+        self.last = {"pair_a": mol_a, "pair_b": mol_b, "p": p, "uniform": u, "accept": acc}
         per_pair = acc.view(len(pairs), self.n_indep).sum(1).tolist()   # one host sync per attempt
         for (a, b), n_acc in zip(pairs, per_pair):
             pt_count(self.acceptance_matrix, a, b, int(n_acc), self.n_indep)
-        if sum(per_pair):
+        if not sum(per_pair):
+            return
+        moved = self.forces == "moved"
+        if not getattr(sim, "use_hip", True):     # gates off: plain torch, parallel_tempering.py:449-480
+            m = acc.bool()
+            rows_a = (mol_a[m, None] * self.n_atoms + torch.arange(self.n_atoms, device=dev)).reshape(-1)
+            rows_b = (mol_b[m, None] * self.n_atoms + torch.arange(self.n_atoms, device=dev)).reshape(-1)
+            ba = beta[mol_a[m]].repeat_interleave(self.n_atoms)[:, None]
+            bb = beta[mol_b[m]].repeat_interleave(self.n_atoms)[:, None]
+            x, v = sim.x.clone(), sim.v.clone()
+            x[rows_a], x[rows_b] = sim.x[rows_b], sim.x[rows_a]
+            v[rows_a] = sim.v[rows_b] * torch.sqrt(ba / bb)
+            v[rows_b] = sim.v[rows_a] * torch.sqrt(bb / ba)
+            sim.x, sim.v = x, v
+            if moved:
+                f = sim.f.clone()
+                f[rows_a], f[rows_b] = sim.f[rows_b], sim.f[rows_a]
+                sim.f = f
+        else:
             pt_swap_local(sim.x, sim.v, mol_a, mol_b, acc, beta, self.n_atoms)
-            # forces and energies travel with their configuration (F depends on the replica's own coordinates only):
-            # the same in-batch swap on the force rows -- its velocity argument is a scratch array -- and a masked swap
-            # of the energies; no force evaluation (see DistributedReplicaExchange)
-            if self._scratch is None or self._scratch.shape != sim.f.shape:
-                self._scratch = torch.zeros_like(sim.f)
-            pt_swap_local(sim.f, self._scratch, mol_a, mol_b, acc, beta, self.n_atoms)
+            if moved:
+                # the same in-batch swap on the force rows -- its velocity argument is a scratch array
+                if self._scratch is None or self._scratch.shape != sim.f.shape:
+                    self._scratch = torch.zeros_like(sim.f)
+                pt_swap_local(sim.f, self._scratch, mol_a, mol_b, acc, beta, self.n_atoms)
+        if moved:
             ea, eb, m = sim.energy[mol_a], sim.energy[mol_b], acc.bool()
             sim.energy[mol_a] = torch.where(m, eb, ea)
             sim.energy[mol_b] = torch.where(m, ea, eb)

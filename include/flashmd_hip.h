@@ -34,7 +34,11 @@ extern "C" {
 const char* fmd_strerror(int code);
 /* ABI version of this library (bumped on any change a caller can observe).
  *   3: status word 3 of fmd_schnet_energy_forces is sticky and must be zeroed by the caller; FMD_ENONFINITE;
- *      fmd_schnet_workspace_bytes no longer depends on the current device (same signatures as 2). */
+ *      fmd_schnet_workspace_bytes no longer depends on the current device (same signatures as 2).
+ *   4: fmd_schnet_desc ends in `flags`.
+ *   5: the only flag is FMD_FLAG_NO_FILTER_STASH (the opt-in tabulated-filter prototype of ABI 4, bit 2, left the
+ *      product: measured at 0.63x of the MFMA path, DESIGN.md section 3 "Round 4"); desc.cutoff must be finite and
+ *      > 0, desc.gamma finite, else FMD_EINVAL. */
 int fmd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -196,7 +200,7 @@ typedef struct fmd_schnet_desc {
                             > 0 = fixed static interleave */
   float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
   float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
-  int32_t flags;         /* 0, or FMD_FLAG_NO_FILTER_STASH (ABI 4) */
+  int32_t flags;         /* 0, or FMD_FLAG_NO_FILTER_STASH; any other bit: FMD_EINVAL (ABI 5) */
 } fmd_schnet_desc;
 /* By default (FMD_PREC_F32 only) the forward pair kernel of every block but the first keeps its filter values W = filt(d) C(d) (fp32, one per
  * list entry and feature: n_mol * max_pairs_per_mol * 512 bytes of workspace per such block, of which the entries a
@@ -204,12 +208,6 @@ typedef struct fmd_schnet_desc {
  * layer 1.  With this flag the workspace stays small and the backward pass recomputes (same results to the last bit:
  * the recomputation runs the same arithmetic). */
 #define FMD_FLAG_NO_FILTER_STASH 1
-/* Opt-in, FMD_PREC_F32 only: the message weight of a block, W(d) = filt(rbf(d)) C(d), is a function of the pair distance
- * alone once the weights are frozen; fmd_schnet_pack tabulates it (one cubic per interval of width 2^e, 1024..2047
- * intervals over [0, cutoff], fp64 evaluation of the filter network and its analytic slope; pack_bytes grows by
- * intervals * 2 KB per block) and the pair kernels interpolate instead of running the filter network on the MFMA.
- * Interpolation error ~1e-8 relative at the 1ENH basis.  Never the default: the reference's arithmetic is the MFMA path. */
-#define FMD_FLAG_TABULATED_FILTER 2
 
 /* Host pointers to the reference's parameter tensors (fp32, nn.Linear [out,in] layout). */
 typedef struct fmd_schnet_block_weights {

@@ -285,55 +285,27 @@ def test_bench_exchange_attempts_fall_inside_a_short_timed_region():
     assert bench.attempt_steps(1, 100) == [1] and bench.attempt_steps(0, 100) == []
 
 
-def test_tabulated_filter_table_reproduces_the_filter_network(golden_dir):
-    """FMD_FLAG_TABULATED_FILTER (opt-in): fmd_schnet_pack appends, per block, one cubic per interval of width 2^e and
-    feature for W(d) = filt(rbf(d)) C(d) (reference models/schnet.py:710-713, mlp.py:41-48).  Host-only check, no GPU:
-    interpolating the packed table at random distances reproduces the fp64 filter network of the golden weights to
-    ~1e-7 of the filter's scale, value AND slope (the slope is what the backward pass will read), and vanishes at the
-    cutoff."""
+def test_engine_descriptor_is_validated_without_a_gpu():
+    """fmd_schnet_pack_bytes only validates and sizes: unknown flag bits (the tabulated-filter prototype's bit of
+    ABI 4 included), a non-finite or non-positive cutoff and a non-finite gamma are FMD_EINVAL (a C caller's
+    uninitialised struct must not reach the kernels)."""
     import ctypes
 
-    import numpy as np
-    import torch
+    from flashmd_amd import _ffi
 
-    from flashmd_amd import _ffi, engine
-    from oracle import schnet_oracle as so
-    import flashmd_amd.schnet as S
+    def desc(**kw):
+        d = _ffi.SchnetDesc()
+        d.hidden, d.num_rbf, d.num_blocks, d.num_out = 128, 50, 3, 3
+        d.out_width[0], d.out_width[1], d.out_width[2] = 128, 64, 1
+        d.embedding_size, d.precision, d.n_split, d.cutoff, d.gamma, d.flags = 100, 0, 0, 5.0, -48.0, 0
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
 
-    p = so.params_from_npz(os.path.join(golden_dir, "weights_L3_R50.npz"))
-    model = S.model_from_params(p)
-    # a CPU model: the constructor only packs (host code) and keeps the buffer where the model lives
-    e0 = engine.FusedSchNetEngine(model, tabulated_filter=False)
-    e1 = engine.FusedSchNetEngine(model, tabulated_filter=True)
-    n0, n1 = e0.packed.numel(), e1.packed.numel()
-    L, F = 3, 128
-    K = (n1 - n0) // (L * F * 4)
-    assert (n1 - n0) == L * K * F * 4 and 1024 <= K < 2048
-    rc = 5.0
-    inv_h = K / rc if abs(K / rc - round(K / rc)) < 1e-9 else None
-    assert inv_h == 256.0   # h = 2^-8 for cutoff 5: k = floor(d / h) and t = d / h - k are exact in fp32
-    tab = e1.packed[n0:].view(L, K, F, 4).double().numpy()
-    assert torch.equal(e0.packed, e1.packed[:n0])
-    g = np.random.default_rng(0)
-    d = np.concatenate([g.uniform(0.05, rc, 400), [rc - 1e-6, rc * (1 - 2.0 ** -20)]])
-    k = np.minimum(np.floor(d * inv_h).astype(int), K - 1)
-    t = d * inv_h - k
-    for l in range(L):
-        blk = p["blocks"][l]
-        x = torch.tensor(d, dtype=torch.float64, requires_grad=True)
-        cen = model.rbf_layer.offset.double()          # the fp32 centres and coefficient the packer was given
-        gamma = float(model.rbf_layer.coeff)
-        C = 0.5 * (torch.cos(np.pi * x / rc) + 1.0)
-        rbf = torch.exp(gamma * (x[:, None] - cen[None, :]) ** 2) * C[:, None]
-        hid = torch.tanh(rbf @ blk["f0_w"].double().t() + blk["f0_b"].double())
-        W = (hid @ blk["f1_w"].double().t()) * C[:, None]                      # [n, 128]
-        a = tab[l][k]                                                          # [n, 128, 4]
-        W_tab = a[..., 0] + t[:, None] * (a[..., 1] + t[:, None] * (a[..., 2] + t[:, None] * a[..., 3]))
-        dW_tab = (a[..., 1] + t[:, None] * (2 * a[..., 2] + 3 * t[:, None] * a[..., 3])) * inv_h
-        scale = float(W.detach().abs().max())
-        err = np.abs(W_tab - W.detach().numpy()).max()
-        assert err < 5e-7 * scale, (err, scale)     # fp32 rounding of four coefficients; the interpolation itself ~1e-8
-        for f in (0, 17, 127):
-            (gw,) = torch.autograd.grad(W[:, f].sum(), x, retain_graph=True)
-            assert np.abs(dW_tab[:, f] - gw.numpy()).max() < 2e-5 * float(gw.abs().max())
-        assert np.abs(W_tab[-2:]).max() < 1e-9 * max(scale, 1.0)
+    lib = _ffi.lib()
+    assert lib.fmd_abi_version() == _ffi.ABI_VERSION == 5
+    assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc())) > 0
+    assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc(flags=_ffi.FLAG_NO_FILTER_STASH))) > 0
+    for bad in (dict(flags=2), dict(flags=3), dict(flags=1 << 20), dict(cutoff=0.0), dict(cutoff=-1.0),
+                dict(cutoff=float("inf")), dict(cutoff=float("nan")), dict(gamma=float("nan")), dict(gamma=float("inf"))):
+        assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc(**bad))) == -1, bad

@@ -840,14 +840,13 @@ def test_engine_from_state_dict_file(params, golden_dir, tmp_path):
     assert re < 2e-5 and rf < 2e-5
 
 
-@pytest.mark.parametrize("precision", ["f32", "w16a16"])
 @pytest.mark.parametrize("shape", ["8x269", "ragged", "fs_2x400"])
-def test_filter_stash_matches_recomputation(params, precision, shape):
+def test_filter_stash_matches_recomputation(params, shape, precision="f32"):
     """The default engine keeps the forward kernels' filter values for the backward kernels of blocks 1.. (the stash,
     EdgeArgs::wst); FMD_FLAG_NO_FILTER_STASH recomputes filter layer 1 there as rounds 1-3 did.  The stash holds exactly
     what the recomputation produces (same MFMA sequence on the same operands), so energies AND forces must agree to the
-    last bit -- in both precisions, for ragged batches (work items that hand tiles to other workgroups) and in
-    feature-split mode (400 beads: two workgroups per molecule, 64 features each)."""
+    last bit -- for ragged batches (work items that hand tiles to other workgroups) and in feature-split mode (400
+    beads: two workgroups per molecule, 64 features each).  fp32-grade precision only: W16A16 has no stash (next test)."""
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
@@ -874,6 +873,24 @@ def test_filter_stash_matches_recomputation(params, precision, shape):
     assert torch.equal(f1, f2)
     e3, f3 = stash.energy_forces(P, T, Q, mb)   # and a second call reuses the stash buffer
     assert torch.equal(f1, f3)
+    # the stash is what makes the workspaces differ: (L - 1) blocks x molecules x list capacity x 512 bytes
+    assert stash._ws.numel() > plain._ws.numel()
+
+
+def test_w16a16_engine_has_no_filter_stash(params):
+    """W16A16 never allocates a stash (csrc: carve_ws; the stash kernels are not even instantiated for it): the
+    workspace is the same size with and without the flag."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    pos, types, ptr = so.synth_batch(4, 100, 5.0)
+    model = S.model_from_params(params).to(DEV)
+    a = engine.FusedSchNetEngine(model, precision="w16a16")
+    b = engine.FusedSchNetEngine(model, precision="w16a16", filter_stash=False)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    e1, f1 = a.energy_forces(P, T, Q, 100)
+    e2, f2 = b.energy_forces(P, T, Q, 100)
+    assert a._ws.numel() == b._ws.numel() and torch.equal(f1, f2) and torch.equal(e1, e2)
 
 
 @pytest.mark.parametrize("precision,steps_per_graph", [("f32", 1), ("f32", 3), ("w16a16", 1)])
@@ -921,27 +938,6 @@ def test_captured_timestep_is_bit_identical(params, precision, steps_per_graph):
     assert torch.equal(eager.x, graph.x)
 
 
-@pytest.mark.parametrize("case", ["case_small_3x37", "case_1enh_2x269", "case_ragged"])
-def test_tabulated_filter_mode_vs_reference_vectors(params, golden_dir, case):
-    """Opt-in FMD_FLAG_TABULATED_FILTER: the pair kernels interpolate W(d) = filt(rbf(d)) C(d) from the table packed
-    with the weights (csrc/fmd_engine_tab.hip) instead of running the filter network on the MFMA.  Same golden vectors,
-    same bar as the MFMA formulation: forces <= 2e-5 against the reference's fp64 result."""
-    import flashmd_amd.schnet as S
-    from flashmd_amd import engine
-
-    z = np.load(os.path.join(golden_dir, case + ".npz"))
-    pos, types, ptr = (torch.from_numpy(z[k]).to(DEV) for k in ("pos", "types", "ptr"))
-    model = S.model_from_params(params).to(DEV)
-    eng = engine.FusedSchNetEngine(model, tabulated_filter=True)
-    mb = int((ptr[1:] - ptr[:-1]).max())
-    e, f = eng.energy_forces(pos, types, ptr, mb)
-    re, rf = _relerr(e, f, z["energy_ref64"], z["forces_ref64"])
-    print(f"{case}: tabulated filter, energy {re:.2e} forces {rf:.2e}")
-    assert re < 2e-5 and rf < 2e-5
-    e2, f2 = eng.energy_forces(pos, types, ptr, mb)
-    assert torch.equal(e, e2) and torch.equal(f, f2)
-
-
 def test_local_replica_exchange_moves_forces_with_the_configurations(params):
     """Parallel tempering with all temperatures in one batch (the reference's layout, parallel_tempering.py:204-220):
     an exchange swaps positions, rescaled velocities (reference :467-477) AND the forces / energies of the accepted
@@ -964,7 +960,7 @@ def test_local_replica_exchange_moves_forces_with_the_configurations(params):
     betas = [1.67, 1.3, 1.0, 0.8]
     beta = torch.tensor(betas, device=DEV).repeat_interleave(n_indep)
     sim = simulate.LangevinSimulation(force, P, torch.full((P.shape[0],), 12.0, device=DEV), beta, A, seed=3)
-    ex = simulate.LocalReplicaExchange(betas, n_indep, A, seed=1)
+    ex = simulate.LocalReplicaExchange(betas, n_indep, A, seed=1, forces="moved")
     moved = 0
     for attempt in range(6):
         for _ in range(3):

@@ -62,7 +62,7 @@ elif mode == "pt":
     ptr_l = torch.arange(n_indep + 1) * A
     ff = force_fn_for(types[sl], ptr_l)
     sim = simulate.LangevinSimulation(ff, pos[sl] + 0.05 * rank, masses[sl], torch.full((n_indep,), betas[rank]), A, seed=11 + rank)
-    ex = simulate.DistributedReplicaExchange(betas, n_indep, A, seed=5)
+    ex = simulate.DistributedReplicaExchange(betas, n_indep, A, seed=5, forces="moved")
     x0, v0, u0 = sim.x.clone(), sim.v.clone(), sim.energy.clone()
     allx = [torch.empty_like(x0) for _ in range(world)]; dist.all_gather(allx, x0)
     allv = [torch.empty_like(v0) for _ in range(world)]; dist.all_gather(allv, v0)
@@ -105,7 +105,7 @@ elif mode in ("pt4", "pt8"):
     ptr_l = torch.arange(n_indep + 1) * A
     ff = force_fn_for(types[sl], ptr_l)
     sim = simulate.LangevinSimulation(ff, pos[sl] + 0.03 * rank, masses[sl], torch.full((n_indep,), betas[rank]), A, seed=11 + rank)
-    ex = simulate.DistributedReplicaExchange(betas, n_indep, A, seed=5)
+    ex = simulate.DistributedReplicaExchange(betas, n_indep, A, seed=5, forces="moved")
     expected = torch.zeros(world, world, dtype=torch.int64)
     ok, evals = True, 0
     counted = [0]
