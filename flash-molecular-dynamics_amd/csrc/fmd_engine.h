@@ -59,7 +59,11 @@ constexpr int TILE_FLOATS = 32 * LDA;
 constexpr size_t MAX_LDS_BYTES = 160 * 1024;
 constexpr int MAX_LDS_ROWS = 283; // beads per molecule whose aggregate fits the 160 KB LDS next to the tile buffer
 constexpr int MAX_LDS_ROWS_FS = 535;  // ... in feature-split mode (64 features per workgroup, any num_rbf)
-constexpr int Q0_FLOATS = 4 * 4 * 64 * 4;   // split operand, K padded to 64: [wave][k-step of 16][lane] x 8 halves (16 B)
+constexpr int MAX_RBF = 128;                // Gaussians of the basis the pair kernels take (k-steps of 16: NS0 = 2, 4 or 8)
+constexpr int Q0_FLOATS = 4 * 8 * 64 * 4;   // split operand, K padded to 64 or 128: [wave][k-step of 16][lane] x 8 halves (16 B)
+// record of (wave w, k-step s) of a packed layer-0 operand: 4 k-steps per wave up to 64 Gaussians, 8 beyond
+template <int NS0>
+constexpr int q0_rec(int w, int s) { return w * (NS0 > 4 ? 8 : 4) + s; }
 constexpr int Q1_FLOATS = 4 * 8 * 64 * 4;   // same for K = 128
 constexpr int SLICE = 2 * Q1_FLOATS;        // floats of one packed 128x128 node operand: hi record, lo record
 
@@ -88,7 +92,7 @@ struct EdgeArgs {
   const float *q0ch, *q0cl;                          // centre-weighted W0 (backward, shared-Gaussian form)
   float c0;                                          // cutoff / 2
   int nb;                                            // ceil(num_rbf / 8): half k-steps that hold Gaussians
-  const float* centers;    // [64]
+  const float* centers;    // [MAX_RBF]
   float* slabs;            // [n_split + 1][N,128] partial aggregates (fwd: agg, bwd: gx1); the last: extra pieces
   int64_t slab_stride;
   float gamma, rc;
@@ -396,22 +400,6 @@ __device__ __forceinline__ void mfma_split(const f16x8& ah, const f16x8& al, con
   acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2, 0, 0, 0);
 }
 
-
-// The same GEMM with the operand's fragments already in registers: lets a kernel that chains several GEMMs per
-// tile issue the NEXT operand's loads (L2, ~1-2 us) before it runs the current one.
-struct BFrag {
-  f16x8 h[8], l[8];
-};
-__device__ __forceinline__ void load_bfrag(BFrag& b, const float* pk, int w, int lane) {
-  asm volatile("" : "+s"(pk));  // the loads stay where they are written (not hoisted out of the tile loop)
-  const f16x8* bh = reinterpret_cast<const f16x8*>(pk) + (int64_t)w * 8 * 64 + lane;
-  const f16x8* bl = reinterpret_cast<const f16x8*>(pk + Q1_FLOATS) + (int64_t)w * 8 * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    b.h[s] = bh[s * 64];
-    b.l[s] = bl[s * 64];
-  }
-}
 
 // Centre-row sum of a segment.  A 32-entry tile is four 8-entry segments; the lower and the upper lane half hold
 // four entries each (register r = 4q + e <-> entry 8q + 4h + e).  Usually both halves belong to one centre and the

@@ -54,13 +54,16 @@ __device__ __forceinline__ f16x8 gw_frag(gw_lds_ptr a1, gw_lds_ptr a2) {
 template <int NS0, bool NEED_GX1, bool FIRST, bool SHARE, bool HALF, bool FS, bool STASH>
 __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
+  // 65..128 Gaussians (NS0 = 8): every producer forms the Gaussians of its own pairs (the shared form deals ONE k-step to
+  // each of four waves, and its centre-weighted operand would not fit the register file next to eight k-steps of W0)
+  static_assert(NS0 <= 4 || (!SHARE && !FS), "NS0 = 8 runs in the per-wave Gaussian form, whole-aggregate mode");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
   // the gW tile reuses the two fp16 tiles (hi, lo), [pair][feature]
   float* red = smem + TILE_FLOATS + 128;                         // [4][32]
-  float* cen_l = red + 128;                                      // [64] rbf centres
-  float* b0_l = cen_l + 64;                                      // [128] filter layer-0 bias
+  float* cen_l = red + 128;                                      // [MAX_RBF] rbf centres
+  float* b0_l = cen_l + MAX_RBF;                                 // [128] filter layer-0 bias
   // SHARE: the Gaussians of a tile are computed once, by the consumers (consumer w: k-step w), and cross
   // LDS as split fragments [half k-step][hi, lo][pair] x 16 B; the producers then run W0 and
   // Wc = W0 diag(centre - c0) on the same fragments (W0 (raw (d - centre)) = (d - c0) W0 raw - Wc raw).
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   constexpr int AW = FS ? 64 : F;  // gx1 row width kept in LDS
   if (NEED_GX1)
     for (int i = tid * 4; i < n * AW; i += 2048) *reinterpret_cast<f32x4*>(gx1 + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (tid < 64) cen_l[tid] = a.centers[tid];
+  if (tid < MAX_RBF) cen_l[tid] = a.centers[tid];
   if (tid < 128) b0_l[tid] = a.b0[tid] * (2.0f * LOG2E);  // pre-multiplied: tanh(z) = 1 - 2 / (exp2(2 log2(e) z) + 1)
   const uint32_t* poi = a.poi + (int64_t)m * a.cap;
   const uint32_t* poj = a.poj + (int64_t)m * a.cap;
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
-        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane];
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane];
         if constexpr (SHARE && !HALF) {
-          ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[(w * 4 + s) * 64 + lane];
-          acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[(w * 4 + s) * 64 + lane];
+          ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[q0_rec<NS0>(w, s) * 64 + lane];
+          acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[q0_rec<NS0>(w, s) * 64 + lane];
         }
       }
       constexpr int NKU = FS ? 4 : 8;          // k-steps of the u GEMM: the features of gW this workgroup holds
@@ -618,6 +621,22 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           X.oi[q] = oi_m[q] + col4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+          if (FMD_DBG_SKIP(a, 6)) {   // diagnostic build: no row gathers (timing only: what the address path costs)
+            X.xi[q] = 1.0f; X.gi[q] = 0.25f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { X.xj[4 * q + e] = 0.5f; X.gj[4 * q + e] = 0.125f; }
+            return;
+          }
+          if (FMD_DBG_SKIP(a, 7)) {   // diagnostic build: half the gathers (x1 only)
+            X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
+            X.gi[q] = X.xi[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
+              X.gj[4 * q + e] = X.xj[4 * q + e];
+            }
+            return;
+          }
           X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
           X.gi[q] = *reinterpret_cast<const float*>(gab + X.oi[q]);
 #pragma unroll
@@ -705,32 +724,42 @@ namespace fmd_eng {
   M_(false, true, true, false, true, false) M_(false, false, true, false, true, false)         \
   M_(false, true, true, true, true, false) M_(false, false, true, true, true, false)
 
+// NS0 = 8 (65..128 Gaussians): the per-wave Gaussian form in whole-aggregate mode only
+#define FMD_BWD_WIDE(M_)                                                                        \
+  M_(true, true, false, false, false, false) M_(true, false, false, false, false, false)       \
+  M_(true, true, false, false, false, true) M_(true, false, false, false, false, true)         \
+  M_(true, true, false, true, false, false) M_(true, false, false, true, false, false)         \
+  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
+  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)
+
 template <int NS0>
 static int set_attrs() {
 #define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                     \
   if (hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_>,                  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)      \
     return FMD_ELAUNCH;
-  FMD_BWD_ALL(FMD_ONE)
+  if constexpr (NS0 > 4) { FMD_BWD_WIDE(FMD_ONE) } else { FMD_BWD_ALL(FMD_ONE) }
 #undef FMD_ONE
   return FMD_OK;
 }
 int setup_edge_bwd_attrs() {
-  const int rc = set_attrs<2>();
-  return rc != FMD_OK ? rc : set_attrs<4>();
+  int rc = set_attrs<2>();
+  if (rc == FMD_OK) rc = set_attrs<4>();
+  if (rc == FMD_OK) rc = set_attrs<8>();
+  return rc;
 }
 
 template <int NS0>
 static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 grid, hipStream_t s) {
   // [tile region][red 128][centres 64][bias 128]([fragments])[gx1 rows]; block 0 (no gx1) keeps no aggregate
-  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
+  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + MAX_RBF + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
   const size_t frag = (size_t)a.nb * 1024;
   // shared-Gaussian form when its fragment region fits next to the aggregate (block 0 keeps none)
   // (block 0, whole-aggregate mode: the pipelined form -- second fragment buffer, second gW image, second partial sums)
   const size_t lds_sh = need ? lds + frag
-                             : (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128) * sizeof(float) + frag +
+                             : (size_t)(TILE_FLOATS + 128 + 128 + MAX_RBF + 128) * sizeof(float) + frag +
                                    (a.fs ? 0 : frag + (size_t)(4096 + 128) * sizeof(float));
-  const bool share = lds_sh <= MAX_LDS_BYTES;
+  const bool share = NS0 <= 4 && lds_sh <= MAX_LDS_BYTES;
   const bool stash = need && !half && a.wst != nullptr;
   if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
 #define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                  \
@@ -738,7 +767,7 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
     edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a);      \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                         \
   }
-  FMD_BWD_ALL(FMD_ONE)
+  if constexpr (NS0 > 4) { FMD_BWD_WIDE(FMD_ONE) } else { FMD_BWD_ALL(FMD_ONE) }
 #undef FMD_ONE
   return FMD_EUNSUPPORTED;
 }
@@ -746,8 +775,9 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
 int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol,
                     hipStream_t s) {
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
-  return num_rbf <= 32 ? launch_bwd<2>(a, half, need_gx1, first, grid, s)
-                       : launch_bwd<4>(a, half, need_gx1, first, grid, s);
+  return num_rbf <= 32   ? launch_bwd<2>(a, half, need_gx1, first, grid, s)
+         : num_rbf <= 64 ? launch_bwd<4>(a, half, need_gx1, first, grid, s)
+                         : launch_bwd<8>(a, half, need_gx1, first, grid, s);
 }
 
 }  // namespace fmd_eng

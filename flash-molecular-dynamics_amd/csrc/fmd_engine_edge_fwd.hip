@@ -36,6 +36,7 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 template <int NS0, bool HALF, bool FS, bool SH, bool STASH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
+  static_assert(NS0 <= 4 || (!SH && !FS), "NS0 = 8 runs in the per-wave Gaussian form, whole-aggregate mode");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
       const float gl = a.gamma * LOG2E;
 #pragma unroll
       for (int s = 0; s < NS0; ++s) {
-        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[(w * 4 + s) * 64 + lane];
-        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[(w * 4 + s) * 64 + lane];
+        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane];
+        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane];
         if (!SH) {
           cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
           cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
@@ -397,6 +398,12 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             X.oi[q] = oi_m[q] + col4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
+            if (FMD_DBG_SKIP(a, 6)) {   // diagnostic build: no row gathers (timing only: what the address path costs)
+              X.xi[q] = 1.0f;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = 0.5f;
+              return;
+            }
             X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
@@ -502,8 +509,13 @@ static int set_fwd_attrs() {
   if (hipFuncSetAttribute((const void*)edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH>,                        \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)       \
     return FMD_ELAUNCH;
-  FMD_FWD_F32(FMD_ONE)
-  if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
+  if constexpr (NS0 > 4) {   // 65..128 Gaussians: per-wave Gaussian form, whole-aggregate mode
+    FMD_ONE(false, false, false)
+    if constexpr (!STASH) { FMD_ONE(true, false, false) }
+  } else {
+    FMD_FWD_F32(FMD_ONE)
+    if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
+  }
 #undef FMD_ONE
   return FMD_OK;
 }
@@ -512,33 +524,43 @@ int setup_edge_fwd_attrs() {
   if (rc == FMD_OK) rc = set_fwd_attrs<2, true>();
   if (rc == FMD_OK) rc = set_fwd_attrs<4, false>();
   if (rc == FMD_OK) rc = set_fwd_attrs<4, true>();
+  if (rc == FMD_OK) rc = set_fwd_attrs<8, false>();
+  if (rc == FMD_OK) rc = set_fwd_attrs<8, true>();
   return rc;
 }
 
 template <int NS0, bool STASH>
 static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   // [tile region][red 128][centres 64][bias 128][aggregate rows] (the backward kernel's carve: one size for both)
-  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + 64 + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
+  const size_t lds = (size_t)(TILE_FLOATS + 128 + 128 + MAX_RBF + 128 + a.max_beads * (a.fs ? 64 : F)) * sizeof(float);
   // shared-Gaussian form when its fragment region fits next to the aggregate
   // W16A16: [tile region = two hidden planes][two fragment buffers of nb x 512 B][aggregate rows] (the same size)
   const size_t lds_sh = (size_t)(TILE_FLOATS + 128 + a.nb * 256 + a.max_beads * F) * sizeof(float);
-  const bool sh = !a.fs && lds_sh <= MAX_LDS_BYTES;
-  if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
+  const bool sh = NS0 <= 4 && !a.fs && lds_sh <= MAX_LDS_BYTES;
+  if (lds > MAX_LDS_BYTES || (NS0 > 4 && a.fs)) return FMD_EUNSUPPORTED;
 #define FMD_ONE(H_, FS_, SH_)                                                                     \
   if (half == H_ && a.fs == FS_ && sh == SH_) {                                                   \
     edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH><<<grid, 512, (SH_) ? lds_sh : lds, s>>>(a);  \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                \
   }
-  FMD_FWD_F32(FMD_ONE)
-  if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
+  if constexpr (NS0 > 4) {
+    FMD_ONE(false, false, false)
+    if constexpr (!STASH) { FMD_ONE(true, false, false) }
+  } else {
+    FMD_FWD_F32(FMD_ONE)
+    if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
+  }
 #undef FMD_ONE
   return FMD_EUNSUPPORTED;
 }
 
 int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
-  if (a.wst && !half) return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s) : launch_fwd<4, true>(a, half, grid, s);
-  return num_rbf <= 32 ? launch_fwd<2, false>(a, half, grid, s) : launch_fwd<4, false>(a, half, grid, s);
+  if (a.wst && !half)
+    return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s)
+           : num_rbf <= 64 ? launch_fwd<4, true>(a, half, grid, s) : launch_fwd<8, true>(a, half, grid, s);
+  return num_rbf <= 32 ? launch_fwd<2, false>(a, half, grid, s)
+         : num_rbf <= 64 ? launch_fwd<4, false>(a, half, grid, s) : launch_fwd<8, false>(a, half, grid, s);
 }
 
 }  // namespace fmd_eng

@@ -29,7 +29,7 @@ PackLayout pack_layout(const fmd_schnet_desc* d) {
   PackLayout L;
   L.emb = 0;
   L.centers = (int64_t)d->embedding_size * F;
-  L.blocks = L.centers + 64;
+  L.blocks = L.centers + MAX_RBF;
   L.block_stride = BLOCK_FLOATS;
   L.outs = L.blocks + (int64_t)d->num_blocks * BLOCK_FLOATS;
   L.out_stride = OUT_FLOATS;
@@ -188,7 +188,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
 
 bool desc_ok(const fmd_schnet_desc* d) {
   if (!d) return false;
-  if (d->hidden != F || d->num_rbf < 2 || d->num_rbf > 64) return false;
+  if (d->hidden != F || d->num_rbf < 2 || d->num_rbf > MAX_RBF) return false;
   if (d->num_blocks < 1 || d->num_blocks > 8) return false;
   if (d->num_out < 2 || d->num_out > 3) return false;
   for (int k = 0; k < d->num_out; ++k)
@@ -260,6 +260,7 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
         out[L.emb_x1 + (int64_t)t * F + o] = (float)acc;
       }
   }
+  const int q0_steps = desc->num_rbf > 64 ? 8 : 4;   // k-steps of 16 per wave in the layer-0 records (q0_rec)
   for (int l = 0; l < desc->num_blocks; ++l) {
     const fmd_schnet_block_weights& b = wt->blocks[l];
     if (!b.lin1_w || !b.f0_w || !b.f0_b || !b.f1_w || !b.lin2_w || !b.lin2_b || !b.lin_w || !b.lin_b)
@@ -276,14 +277,14 @@ extern "C" int fmd_schnet_pack(const fmd_schnet_desc* desc, const fmd_schnet_wei
     pack_node(out + o.l3, b.lin_w, F, F, false);
     memcpy(out + o.b3, b.lin_b, F * sizeof(float));
     pack_node(out + o.l3t, b.lin_w, F, F, true);
-    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, 4, false, 1.0f);
+    pack_split(out + o.q0h, out + o.q0l, b.f0_w, F, desc->num_rbf, q0_steps, false, 1.0f);
     {  // Wc[f][k] = (centre_k - cutoff/2) W0[f][k]:  W0 (raw (d - centre)) = (d - cutoff/2) W0 raw - Wc raw
       std::vector<float> wc((size_t)F * desc->num_rbf);
       const float c0 = 0.5f * desc->cutoff;
       for (int f = 0; f < F; ++f)
         for (int k = 0; k < desc->num_rbf; ++k)
           wc[(size_t)f * desc->num_rbf + k] = (centers[k] - c0) * b.f0_w[(size_t)f * desc->num_rbf + k];
-      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, 4, false, 1.0f);
+      pack_split(out + o.q0ch, out + o.q0cl, wc.data(), F, desc->num_rbf, q0_steps, false, 1.0f);
     }
     pack_split(out + o.q1h, out + o.q1l, b.f1_w, F, F, 8, false, 1.0f);
     pack_split(out + o.q1th, out + o.q1tl, b.f1_w, F, F, 8, true);

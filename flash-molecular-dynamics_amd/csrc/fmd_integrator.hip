@@ -1,5 +1,5 @@
 // Row N1: Langevin BAOAB elementwise halves around the force call (reference
-// simulation/langevin.py:136-170) and row (e): in-place parallel-tempering swap of accepted replica
+// simulation/langevin.py:136-170), the overdamped step (:315-434) and row (e): in-place parallel-tempering swap of accepted replica
 // pairs (reference simulation/parallel_tempering.py:415-481).  Pure HBM streaming, 12 B/bead/array.
 #include "fmd_common.h"
 
@@ -44,6 +44,18 @@ __global__ __launch_bounds__(256) void verlet_pre_kernel(float* __restrict__ x, 
   const float vh = v[i] + 0.5f * dt * f[i] / masses[i / 3];
   x[i] = x[i] + dt * vh;
   v[i] = vh;
+}
+
+// overdamped Langevin / Brownian step (reference simulation/langevin.py:370-372,417-421):
+// D = 1 / beta / friction, dtau = D dt, x <- x + f dtau + sqrt(2 dtau) noise
+__global__ __launch_bounds__(256) void overdamped_kernel(float* __restrict__ x, const float* __restrict__ f,
+                                                         const float* __restrict__ beta_node,
+                                                         const float* __restrict__ noise, int64_t n3, float dt,
+                                                         float friction) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n3) return;
+  const float dtau = (1.0f / beta_node[i / 3] / friction) * dt;
+  x[i] = x[i] + f[i] * dtau + sqrtf(2.0f * dtau) * noise[i];
 }
 
 // one workgroup per proposed pair; untouched when the pair was rejected
@@ -103,6 +115,18 @@ extern "C" int fmd_verlet_pre(float* x, float* v, const float* f, const float* m
   if (!x || !v || !f || !masses) return FMD_EINVAL;
   const int64_t n3 = n_nodes * 3;
   verlet_pre_kernel<<<(unsigned)((n3 + 255) / 256), 256, 0, fmd_stream(stream)>>>(x, v, f, masses, n3, dt);
+  FMD_CHECK_LAUNCH();
+  return FMD_OK;
+}
+
+extern "C" int fmd_overdamped_step(float* x, const float* f, const float* beta_node, const float* noise,
+                                   int64_t n_nodes, float dt, float friction, void* stream) {
+  if (n_nodes < 0 || !(friction > 0.f)) return FMD_EINVAL;
+  if (n_nodes == 0) return FMD_OK;
+  if (!x || !f || !beta_node || !noise) return FMD_EINVAL;
+  const int64_t n3 = n_nodes * 3;
+  overdamped_kernel<<<(unsigned)((n3 + 255) / 256), 256, 0, fmd_stream(stream)>>>(x, f, beta_node, noise, n3, dt,
+                                                                                  friction);
   FMD_CHECK_LAUNCH();
   return FMD_OK;
 }

@@ -46,6 +46,7 @@ SIGNATURES = {
     "fmd_langevin_pre": (I32, [P, P, P, P, P, P, I64, F32, F32, F32, P]),
     "fmd_langevin_post": (I32, [P, P, P, I64, F32, P]),
     "fmd_verlet_pre": (I32, [P, P, P, P, I64, F32, P]),
+    "fmd_overdamped_step": (I32, [P, P, P, P, I64, F32, F32, P]),
     "fmd_prior_energy_forces": (I32, [P, P, I64, I64, I32, P, P, I32, P, P, I64, P, P, P, P]),
     "fmd_prior_pairs_energy_forces": (I32, [P, P, I64, I64, I32, P, P, P, I64, P, P, P, P]),
     "fmd_pt_swap_local": (I32, [P, P, P, P, P, P, I64, I64, P]),

@@ -23,6 +23,8 @@ from . import _ffi
 from ._ffi import call, ptr, stream
 
 MAX_BEADS = 535   # 283 with the whole aggregate in one workgroup's LDS, 535 in feature-split mode
+MAX_BEADS_WHOLE = 283
+MAX_RBF = 128     # csrc/fmd_engine.h MAX_RBF; 65..128 Gaussians run in whole-aggregate mode only (no feature split)
 # fmd_schnet_desc.precision (include/flashmd_hip.h)
 PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, fp32-grade (2e-7 per contraction), the default
               "w16a16": 1}     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
@@ -93,8 +95,8 @@ class FusedSchNetEngine:
         blocks = list(model.interaction_blocks)
         if not isinstance(rbf, GaussianBasis) or not isinstance(rbf.cutoff, CosineCutoff):
             raise ValueError("fused engine: needs GaussianBasis with CosineCutoff")
-        if rbf.cutoff.cutoff_lower != 0 or rbf.num_rbf > 64 or rbf.num_rbf < 2:
-            raise ValueError("fused engine: cutoff_lower must be 0 and 2 <= num_rbf <= 64")
+        if rbf.cutoff.cutoff_lower != 0 or rbf.num_rbf > MAX_RBF or rbf.num_rbf < 2:
+            raise ValueError(f"fused engine: cutoff_lower must be 0 and 2 <= num_rbf <= {MAX_RBF}")
         hidden = model.embedding_layer.embedding_dim
         for blk in blocks:
             cut = blk.conv.cutoff
@@ -129,6 +131,8 @@ class FusedSchNetEngine:
 
         self.device = model.embedding_layer.weight.device
         self.cutoff = float(rbf.cutoff.cutoff_upper)
+        # the largest molecule this engine takes: a basis of 65..128 Gaussians has no feature-split mode
+        self.max_beads = MAX_BEADS if rbf.num_rbf <= 64 else MAX_BEADS_WHOLE
         d = _ffi.SchnetDesc()
         d.hidden, d.num_rbf, d.num_blocks, d.num_out = 128, rbf.num_rbf, len(blocks), len(outs)
         for k in range(4):
@@ -188,7 +192,7 @@ class FusedSchNetEngine:
         weights-only ``torch.load`` file; ``prefix=None`` finds the SchNet inside a ``GradientsOut`` / ``SumOut``
         container; ``cutoff``: see ``schnet.model_from_state_dict`` -- hyper-parameters the weights do not encode).
         Raises ValueError when the model is outside the engine's envelope (hidden, filters <= 128,
-        2 <= num_rbf <= 64, 2-3 output linears)."""
+        2 <= num_rbf <= 128, 2-3 output linears)."""
         from .schnet import model_from_state_dict
 
         return cls(model_from_state_dict(sd, prefix, cutoff).to(device).eval(), **kw)
@@ -257,8 +261,8 @@ class FusedSchNetEngine:
                 raise ValueError(f"fused engine: max_beads_per_mol={max_beads_per_mol} but the batch holds a molecule "
                                  f"of {true_max} beads")
             self._bound_key, self._bound_ref = key, mol_ptr
-        if max_beads_per_mol > MAX_BEADS:
-            raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {MAX_BEADS}")
+        if max_beads_per_mol > self.max_beads:
+            raise RuntimeError(f"fused engine: molecule of {max_beads_per_mol} beads > {self.max_beads}")
         # every pair plus <= 7 pad entries per centre (8-entry segments): can never overflow
         a_ = max_beads_per_mol
         cap = max(32, (a_ * (a_ - 1) // 2 + 8 * a_ + 31) // 32 * 32)
@@ -320,7 +324,7 @@ def maybe_engine(model, data):
         ptr_ = data.ptr
         mb = int((ptr_[1:] - ptr_[:-1]).max().item())
         data.max_beads_per_mol = mb
-    if mb > MAX_BEADS:
+    if mb > eng.max_beads:
         return None
     # the engine always builds the full within-cutoff graph: a model whose max_num_neighbors could truncate it, or
     # a batch that brings its own compatible neighbour list (reference models/schnet.py:216-245, 371-380), goes to

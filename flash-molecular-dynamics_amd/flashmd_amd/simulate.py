@@ -44,6 +44,16 @@ def verlet_pre(x, v, f, masses, dt: float):
     call("fmd_verlet_pre", ptr(x), ptr(v), ptr(f), ptr(masses), x.shape[0], float(dt), stream())
 
 
+def overdamped_step(x, f, beta_node, noise, dt: float, friction: float):
+    """in place: x <- x + f D dt + sqrt(2 D dt) noise, D = 1 / (beta friction) (reference simulation/langevin.py:370-372,
+    417-421)"""
+    _ffi.require_gpu(x, f, beta_node, noise)
+    for t in (x, f, beta_node, noise):
+        assert t.is_contiguous() and t.dtype == torch.float32
+    call("fmd_overdamped_step", ptr(x), ptr(f), ptr(beta_node), ptr(noise), x.shape[0], float(dt), float(friction),
+         stream())
+
+
 def pt_swap_local(x, v, mol_a, mol_b, accept, beta_mol, n_atoms: int):
     """In place swap of accepted replica pairs living in one batch (reference
     simulation/parallel_tempering.py:415-481): x[a]<->x[b], v[a]=v[b]*sqrt(beta_a/beta_b),
@@ -397,6 +407,32 @@ class NVESimulation(LangevinSimulation):
         self.x = self.x + dt * v
         self.energy, self.f = self.force_fn(self.x)
         self.v = v + 0.5 * dt * self.f / m
+
+
+class OverdampedSimulation(LangevinSimulation):
+    """Overdamped Langevin (Brownian) dynamics (reference simulation/langevin.py:315-434): no masses, no velocities;
+    x <- x + F D dt + sqrt(2 D dt) noise with D = 1 / (beta friction), then the force call.  Same loop, noise draw,
+    throughput definition, trajectory writer and hipGraph capture as the Langevin class (``v`` stays zero: the reference
+    saves no velocities here either, and the kinetic energy it reports is 0)."""
+
+    def __init__(self, force_fn, pos, beta_mol, n_atoms: int, dt: float = 0.004, friction: float = 1.0,
+                 seed: int = 103838, use_hip: Optional[bool] = None):
+        assert friction > 0   # reference langevin.py:342
+        super().__init__(force_fn, pos, torch.ones(pos.shape[0], device=pos.device), beta_mol, n_atoms, dt=dt,
+                         friction=friction, seed=seed, use_hip=use_hip)
+        self.v.zero_()
+
+    def capture(self, steps_per_graph: int = 1, warmup: int = 2):
+        raise NotImplementedError("capture() records the BAOAB kernels; the overdamped loop runs un-captured")
+
+    def timestep(self):
+        self.draw_noise()
+        if self.use_hip:
+            overdamped_step(self.x, self.f, self.beta_node, self.noise, self.dt, self.friction)
+        else:  # PyTorch path (reference langevin.py:370-372,417-421)
+            dtau = (1.0 / self.beta_node[:, None] / self.friction) * self.dt
+            self.x = self.x + self.f * dtau + torch.sqrt(2 * dtau) * self.noise
+        self.energy, self.f = self.force_fn(self.x)
 
 
 def pt_pairs(n_betas: int, even: bool):

@@ -291,6 +291,10 @@ int fmd_langevin_post(float* v, const float* f, const float* masses, int64_t n_n
  * The second half-kick after the force call is fmd_langevin_post. */
 int fmd_verlet_pre(float* x, float* v, const float* f, const float* masses, int64_t n_nodes, float dt,
                    void* stream);
+/* Overdamped Langevin / Brownian dynamics (simulation/langevin.py:315-434; ABI 5): in place
+ * x <- x + f D dt + sqrt(2 D dt) noise with D = 1 / (beta friction) per bead; noise ~ N(0,1) [N,3]. */
+int fmd_overdamped_step(float* x, const float* f, const float* beta_node, const float* noise, int64_t n_nodes,
+                        float dt, float friction, void* stream);
 int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* mol_b,
                       const uint8_t* accept, const float* beta_mol, int64_t n_pairs, int64_t n_atoms,
                       void* stream);

@@ -840,6 +840,49 @@ def test_engine_from_state_dict_file(params, golden_dir, tmp_path):
     assert re < 2e-5 and rf < 2e-5
 
 
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
+@pytest.mark.parametrize("num_rbf", [65, 100, 128])
+def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
+    """Engine envelope, round 5: a Gaussian basis of 65..128 functions (StandardSchNet takes any, reference
+    models/schnet.py:778-841, radial_basis/gaussian.py:33-75) runs on the engine -- eight k-steps of filter layer 0, every
+    producer forming the Gaussians of its own pairs, whole-aggregate mode (<= 283 beads).  Against the fp64 oracle of the
+    same random model: a ragged batch incl. a 269-bead molecule; stash form (fp32) equal to recomputation; repeat calls
+    bit-identical; a 300-bead molecule is declined (operator path) instead of mis-handled."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    p = so.make_params(num_rbf=num_rbf, num_interactions=2, out_widths=(64,), seed=3, bias_scale=0.1)
+    parts = [so.synth_batch(1, n, 5.0, first_mol=11 + n) for n in (269, 40, 150, 97)]
+    pos = torch.cat([q[0] for q in parts])
+    types = torch.cat([q[1] for q in parts])
+    ptr = torch.tensor([0] + list(np.cumsum([q[0].shape[0] for q in parts])), dtype=torch.int64)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(p, torch.float64), pos.double(), types, ptr)
+    model = S.model_from_params(p).to(DEV)
+    eng = engine.FusedSchNetEngine(model, precision=precision)
+    assert eng.max_beads == 283
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    e, f = eng.energy_forces(P, T, Q, 269)
+    eng.check_status()
+    re, rf = _relerr(e, f, e_o.numpy(), f_o.numpy())
+    print(f"R = {num_rbf} {precision}: energy {re:.2e} forces {rf:.2e} vs the fp64 oracle")
+    tol = 5e-3 if precision == "w16a16" else 2e-5   # (W16A16 against fp64: the band of test_fused_engine_w16a16)
+    assert re < tol and rf < tol
+    e2, f2 = eng.energy_forces(P, T, Q, 269)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    if precision == "f32":
+        plain = engine.FusedSchNetEngine(model, filter_stash=False)
+        e3, f3 = plain.energy_forces(P, T, Q, 269)
+        assert torch.equal(e, e3) and torch.equal(f, f3)
+        # through the reference-shaped entry: the engine answers; a 300-bead molecule goes to the operator path
+        e4, f4 = _run(S, p, pos, types, ptr, engine=True)
+        assert torch.equal(e4.to(DEV), e) and torch.equal(f4.to(DEV), f)
+        big = so.synth_batch(1, 300, 5.0)
+        data = S.Batch(big[0].to(DEV), big[1].to(DEV), big[2].to(DEV))
+        assert engine.maybe_engine(model, data) is None
+        with pytest.raises(RuntimeError):
+            eng.energy_forces(big[0].to(DEV), big[1].to(DEV), big[2].to(DEV), 300)
+
+
 @pytest.mark.parametrize("shape", ["8x269", "ragged", "fs_2x400"])
 def test_filter_stash_matches_recomputation(params, shape, precision="f32"):
     """The default engine keeps the forward kernels' filter values for the backward kernels of blocks 1.. (the stash,

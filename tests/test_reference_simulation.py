@@ -197,3 +197,49 @@ def test_captured_timestep_with_the_full_force_provider(sumout):
     assert torch.equal(eager.x, graph.x) and torch.equal(eager.v, graph.v)
     assert torch.equal(eager.f, graph.f) and torch.equal(eager.energy, graph.energy)
     graph.check_status()
+
+
+# ---------------------------------------------------------------------------------------------- overdamped (round 5)
+@pytest.fixture(scope="module")
+def od_run(golden_dir):
+    return np.load(os.path.join(golden_dir, "overdamped_run.npz"))
+
+
+def _replay_overdamped(od_run, device, use_hip, tol):
+    """OverdampedSimulation fed with the reference's start positions, noise and per-step forces: the reference's own
+    OverdampedSimulation (simulation/langevin.py:315-434, run by oracle/make_golden_overdamped.py) state by state."""
+    from flashmd_amd import simulate
+
+    calls = {"n": 0}
+
+    def force_fn(x):
+        k = calls["n"]
+        calls["n"] += 1
+        f = od_run["forces_in"][0] if k == 0 else od_run["forces"][k - 1]
+        u = od_run["potential"][max(k - 1, 0)]
+        return torch.from_numpy(u.copy()).to(device), torch.from_numpy(f.copy()).to(device)
+
+    class Replay(simulate.OverdampedSimulation):
+        step = 0
+
+        def draw_noise(self):
+            self.noise.copy_(torch.from_numpy(od_run["noise"][self.step]))
+            self.step += 1
+
+    sim = Replay(force_fn, torch.from_numpy(od_run["pos0"]).to(device), torch.from_numpy(od_run["betas"]).to(device),
+                 int(od_run["n_atoms"]), dt=float(od_run["dt"]), friction=float(od_run["friction"]), use_hip=use_hip)
+    for t in range(od_run["pos"].shape[0]):
+        sim.timestep()
+        err = np.abs(sim.x.cpu().numpy() - od_run["pos"][t]).max() / np.abs(od_run["pos"][t]).max()
+        assert err < tol, (t, err)
+    assert float(sim.v.abs().max()) == 0.0
+
+
+def test_overdamped_torch_path_reproduces_the_reference_run(od_run):
+    _replay_overdamped(od_run, "cpu", False, 1e-6)
+
+
+@pytest.mark.gpu
+def test_overdamped_hip_kernel_reproduces_the_reference_run(od_run):
+    """fmd_overdamped_step against the positions the reference's OverdampedSimulation reached."""
+    _replay_overdamped(od_run, "cuda:0", True, 2e-6)

@@ -13,12 +13,13 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--beads", type=int, default=269)
 ap.add_argument("--n-split", type=int, default=0)
 ap.add_argument("--precision", default="f32")
+ap.add_argument("--num-rbf", type=int, default=50)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--replicas", action="store_true", help="every molecule a copy of the first one (no size spread)")
 ap.add_argument("--no-stash", action="store_true", help="FMD_FLAG_NO_FILTER_STASH: the backward kernels recompute filter layer 1")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-model = S.StandardSchNet(S.GaussianBasis(S.CosineCutoff(0.0, 5.0), 50), S.CosineCutoff(0.0, 5.0), [128, 64],
+model = S.StandardSchNet(S.GaussianBasis(S.CosineCutoff(0.0, 5.0), args.num_rbf), S.CosineCutoff(0.0, 5.0), [128, 64],
                          num_interactions=3).to(dev).eval()
 eng = engine.FusedSchNetEngine(model, n_split=args.n_split, precision=args.precision, filter_stash=not args.no_stash)
 names = eng.kernel_names()
