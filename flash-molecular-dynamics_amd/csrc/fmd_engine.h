@@ -103,6 +103,11 @@ struct EdgeArgs {
   // does not recompute layer 1.  Tile t of molecule m: WST_TILE_FLOATS floats at (m * cap / 32 + t) * WST_TILE_FLOATS,
   // record [feature slice 0..3][register group q 0..3][lane 0..63] x 16 bytes = registers 4q .. 4q+3 of that lane.
   float* wst;
+  // Queue mode (more work items than CUs, e.g. a thousand small molecules): one workgroup per CU, each starts with item
+  // <its linear id> and draws the next from this device counter (zeroed by pairs_kernel) until n_items are taken; the item
+  // records are items[2 q].  Null: slot mode, the workgroup's own two records.
+  int* queue;
+  int n_items;
 #ifdef FMD_PHASE_STAMPS
   unsigned long long* stamps;  // diagnostic build (make stamps) only: [workgroup][8 waves][FMD_NSTAMP] cycle totals
   int dbg;                     // diagnostic build only: bit 0 = consumers skip their A-B work, bit 1 = producers skip staging
@@ -166,6 +171,7 @@ struct PairsArgs {
   int max_beads;
   float* forces;           // zeroed here, accumulated by finish
   int* extra_row;          // [N] set to -1 here (sched_body names the rows that have an extra partial)
+  int* queue;              // [16] item counters of the pair kernels' queue mode, zeroed here
 };
 struct SchedArgs {
   const int32_t* npairs;

@@ -93,10 +93,56 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   auto tile_barrier = [&]() { __syncthreads(); };
   int m_own, split;
   wg_to_mol_split(m_own, split);
-  const int* wi = a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);  // work items: see the forward kernel
+  // work items, slot or queue mode, and the per-role instantiation of the body with its weights loaded once per
+  // workgroup: see the forward kernel
+  const int lid_wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+  // (the next item's index crosses the workgroup through the first word of the tile region, which nothing touches between
+  // the last tile of an item and the first barrier of the next: a static __shared__ word would put the kernel over the
+  // 160 KB its dynamic region may already take)
+  volatile int* const next_item_p = reinterpret_cast<volatile int*>(smem);
   FMD_STAMP_DECL
-  for (int it = 0; it < 2; ++it) {
-  const int m = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it]);
+  auto run = [&](auto role_c) {
+  constexpr bool PRODUCER = decltype(role_c)::value;
+  constexpr int NKU = FS ? 4 : 8;          // k-steps of the u GEMM: the features of gW this workgroup holds
+  const int ku0 = FS ? 4 * split : 0;
+  const int lane0 = tid0 & 63;
+  // producers: filter layer 0 (and its centre-weighted twin), W1^T slice of the u GEMM
+  f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
+  f16x8 b1h[8], b1l[8];                    // consumers: filter layer 1 slice (recomputation forms only)
+  if constexpr (PRODUCER) {
+#pragma unroll
+    for (int s = 0; s < NS0; ++s) {
+      a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane0];
+      if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane0];
+      if constexpr (SHARE && !HALF) {
+        ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[q0_rec<NS0>(w, s) * 64 + lane0];
+        acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[q0_rec<NS0>(w, s) * 64 + lane0];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NKU; ++s) {
+      wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + ku0 + s) * 64 + lane0];
+      if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + ku0 + s) * 64 + lane0];
+    }
+  } else if constexpr (NEED_GX1 && !(NEED_GX1 && STASH)) {
+    const int cw0 = FS ? 2 * split + (w & 1) : w;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw0 * 8 + s) * 64 + lane0];
+      if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw0 * 8 + s) * 64 + lane0];
+    }
+  }
+  const bool queued = a.queue != nullptr;   // uniform over the launch
+  const int* const wi_base = queued ? a.items : a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);
+  int q_item = lid_wg;
+  for (int it = 0;; ++it) {
+  if (it) {
+    __syncthreads();  // the flush of the item before has read the aggregate (and next_item_s is written)
+    if (queued) q_item = __builtin_amdgcn_readfirstlane(*next_item_p);
+  }
+  if (queued ? q_item >= a.n_items : it >= 2) break;   // uniform over the workgroup
+  const int* wi = wi_base + (int64_t)(queued ? 2 * q_item : it) * ITEM_INTS;
+  const int m = __builtin_amdgcn_readfirstlane(wi[0]);
   if (m < 0) break;
   // Every per-lane quantity of the body derives from this opaque copy of the thread index: as plain loop invariants
   // the body's address arithmetic would be hoisted in front of the item loop and stay live across BOTH roles
@@ -104,7 +150,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   int tid = tid0;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, h = lane >> 5, c32 = lane & 31;
-  if (it) __syncthreads();  // the flush of the item before has read the aggregate
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -120,35 +165,18 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   const float* pdcut = a.pdc + (int64_t)m * a.cap;
   float* pgd = a.pgd + (int64_t)m * a.cap + (FS ? split * a.pgd_stride : 0);  // FS: one dE/dd slab per half
   const int ntiles = (np + 31) >> 5;  // of the molecule
-  const int T0 = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 1]);
-  const int t_end = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 2]);
-  const int S = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 3]);
-  const int dst_row = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 4]);
+  const int T0 = __builtin_amdgcn_readfirstlane(wi[1]);
+  const int t_end = __builtin_amdgcn_readfirstlane(wi[2]);
+  const int S = __builtin_amdgcn_readfirstlane(wi[3]);
+  const int dst_row = __builtin_amdgcn_readfirstlane(wi[4]);
   const int last_base = (ntiles - 1) * 32;
   const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
   (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
   if (T0 < t_end) {  // uniform over the workgroup
-    if (producer) {
+    if constexpr (PRODUCER) {
       // ------------------------------------------------------------------ producer waves
-      f16x8 a0h[NS0], a0l[NS0], ach[SHARE ? NS0 : 1], acl[SHARE ? NS0 : 1], wth[8], wtl[8];
-#pragma unroll
-      for (int s = 0; s < NS0; ++s) {
-        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane];
-        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane];
-        if constexpr (SHARE && !HALF) {
-          ach[s] = reinterpret_cast<const f16x8*>(a.q0ch)[q0_rec<NS0>(w, s) * 64 + lane];
-          acl[s] = reinterpret_cast<const f16x8*>(a.q0cl)[q0_rec<NS0>(w, s) * 64 + lane];
-        }
-      }
-      constexpr int NKU = FS ? 4 : 8;          // k-steps of the u GEMM: the features of gW this workgroup holds
-      const int ku0 = FS ? 4 * split : 0;
-#pragma unroll
-      for (int s = 0; s < NKU; ++s) {
-        wth[s] = reinterpret_cast<const f16x8*>(a.q1th)[(w * 8 + ku0 + s) * 64 + lane];
-        if (!HALF) wtl[s] = reinterpret_cast<const f16x8*>(a.q1tl)[(w * 8 + ku0 + s) * 64 + lane];
-      }
       // gW hand-over image (see gw_row_off): this lane's two read addresses of k-step 0 in the 16-lane group scheme of
       // ds_read_b64_tr_b16 -- lane 4q+p of a group addresses row (feature) f0 + q, pairs 16 g + 4p .. + 3
       const int tg = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -367,14 +395,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       // ------------------------------------------------------------------ consumer waves
       const bool slice_owner = !FS || w < 2;  // FS: waves 2, 3 only share Gaussians and keep the barriers
       const int cw = FS ? 2 * split + (w & 1) : w;
-      f16x8 b1h[8], b1l[8];
-      if constexpr (NEED_GX1 && !STASHED) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
-          if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
-        }
-      }
       // STASHED: this lane's filter values of a tile, as the forward kernel's consumers stored them
       const float* const wst_m = STASHED ? a.wst + (int64_t)m * a.cap * F + cw * 1024 + lane * 4 : nullptr;
       f32x16 fl_next = zero16();
@@ -621,22 +641,6 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           X.oi[q] = oi_m[q] + col4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
-          if (FMD_DBG_SKIP(a, 6)) {   // diagnostic build: no row gathers (timing only: what the address path costs)
-            X.xi[q] = 1.0f; X.gi[q] = 0.25f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { X.xj[4 * q + e] = 0.5f; X.gj[4 * q + e] = 0.125f; }
-            return;
-          }
-          if (FMD_DBG_SKIP(a, 7)) {   // diagnostic build: half the gathers (x1 only)
-            X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
-            X.gi[q] = X.xi[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
-              X.gj[4 * q + e] = X.xj[4 * q + e];
-            }
-            return;
-          }
           X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
           X.gi[q] = *reinterpret_cast<const float*>(gab + X.oi[q]);
 #pragma unroll
@@ -697,7 +701,11 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
     }
   }
   (void)dst_row;
+  if (queued && tid0 == 0) *next_item_p = (int)atomicAdd(a.queue, 1) + n_wg;   // read behind the next item's first barrier
   }  // work items
+  };  // run
+  if (producer) run(std::true_type{});
+  else run(std::false_type{});
   FMD_STAMP_FLUSH(a, wave)
 }
 

@@ -63,11 +63,58 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   };
   int m_own, split;
   wg_to_mol_split(m_own, split);
-  // this workgroup's work items (sched_body): runs of tiles of one molecule, each with its own aggregate and slab
-  const int* wi = a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);
+  // This workgroup's work items (sched_body): runs of tiles of one molecule, each with its own aggregate and slab.
+  // Slot mode (a.queue == null): the two records of this workgroup.  Queue mode (batches with more items than CUs, round
+  // 5): the launch has one workgroup per CU; workgroup k starts with item k and draws further items from a device
+  // counter -- an item's result lands in its own slab rows whoever computes it, so the schedule does not touch the bits.
+  const int lid_wg = blockIdx.y * gridDim.x + blockIdx.x, n_wg = gridDim.x * gridDim.y;
+  // (the next item's index crosses the workgroup through the first word of the tile region, which nothing touches between
+  // the last tile of an item and the first barrier of the next: a static __shared__ word would put the kernel over the
+  // 160 KB its dynamic region may already take)
+  volatile int* const next_item_p = reinterpret_cast<volatile int*>(smem);
   FMD_STAMP_DECL
-  for (int it = 0; it < 2; ++it) {
-  const int m = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it]);
+  // The body is instantiated once per wave role (generic lambda): a role's weight fragments are loaded ONCE per
+  // workgroup, in front of the item loop, and stay in registers for all of its items -- with the roles as the outer
+  // structure they are live in their own role only (declared in front of a loop that contains both roles they would be
+  // live across both and spill: see the note on the thread index below).
+  auto run = [&](auto role_c) {
+  constexpr bool PRODUCER = decltype(role_c)::value;
+  const int lane0 = tid0 & 63, h0 = lane0 >> 5;
+  f16x8 a0h[NS0], a0l[NS0];                      // producers: filter layer 0 (split), centres, bias
+  f32x4 cen[SH ? 1 : 2 * NS0], b0r[4];
+  f16x8 b1h[8], b1l[8];                          // consumers: filter layer 1 slice (split)
+  if constexpr (PRODUCER) {
+#pragma unroll
+    for (int s = 0; s < NS0; ++s) {
+      a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane0];
+      if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane0];
+      if (!SH) {
+        cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h0);
+        cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h0 + 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)  // bias pre-multiplied by 2 log2(e): tanh(z) = 1 - 2 / (exp2(2 log2(e) z) + 1)
+      b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h0) * (2.0f * LOG2E);
+  } else if (!(FS && w >= 2)) {
+    const int cw0 = FS ? 2 * split + w : w;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw0 * 8 + s) * 64 + lane0];
+      if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw0 * 8 + s) * 64 + lane0];
+    }
+  }
+  const bool queued = a.queue != nullptr;   // uniform over the launch
+  const int* const wi_base = queued ? a.items : a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);
+  int q_item = lid_wg;
+  for (int it = 0;; ++it) {
+  if (it) {
+    __syncthreads();  // the flush of the item before has read the aggregate (and next_item_s is written)
+    if (queued) q_item = __builtin_amdgcn_readfirstlane(*next_item_p);
+  }
+  if (queued ? q_item >= a.n_items : it >= 2) break;   // uniform over the workgroup
+  const int* wi = wi_base + (int64_t)(queued ? 2 * q_item : it) * ITEM_INTS;
+  const int m = __builtin_amdgcn_readfirstlane(wi[0]);
   if (m < 0) break;
   // Every per-lane quantity of the body derives from this opaque copy of the thread index: as plain loop invariants
   // the body's address arithmetic would be hoisted in front of the item loop and stay live across BOTH roles
@@ -75,7 +122,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   int tid = tid0;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, h = lane >> 5, c32 = lane & 31;
-  if (it) __syncthreads();  // the flush of the item before has read the aggregate
   const int64_t a0 = a.mol_ptr[m];
   const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
@@ -86,33 +132,19 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   const float* pdist = a.pd + (int64_t)m * a.cap;
   const float* pcut = a.pc + (int64_t)m * a.cap;
   const int ntiles = (np + 31) >> 5;  // of the molecule: prefetches past the item's end stay inside its list
-  const int T0 = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 1]);     // the item's first tile,
-  const int t_end = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 2]);  // end,
-  const int S = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 3]);      // tile stride
-  const int dst_row = __builtin_amdgcn_readfirstlane(wi[ITEM_INTS * it + 4]);
+  const int T0 = __builtin_amdgcn_readfirstlane(wi[1]);     // the item's first tile,
+  const int t_end = __builtin_amdgcn_readfirstlane(wi[2]);  // end,
+  const int S = __builtin_amdgcn_readfirstlane(wi[3]);      // tile stride
+  const int dst_row = __builtin_amdgcn_readfirstlane(wi[4]);
   const int last_base = (ntiles - 1) * 32;
   const int drop_l0 = FMD_DROP(a, 2), drop_l1 = FMD_DROP(a, 4);  // diagnostic build: two-product variants
   (void)drop_l0; (void)drop_l1;
   __syncthreads();
   FMD_STAMP_START
   if (T0 < t_end) {  // uniform over the workgroup
-    if (producer) {
+    if constexpr (PRODUCER) {
       // ------------------------------------------------------------------ producer waves
-      f16x8 a0h[NS0], a0l[NS0];
-      f32x4 cen[SH ? 1 : 2 * NS0], b0r[4];
       const float gl = a.gamma * LOG2E;
-#pragma unroll
-      for (int s = 0; s < NS0; ++s) {
-        a0h[s] = reinterpret_cast<const f16x8*>(a.q0h)[q0_rec<NS0>(w, s) * 64 + lane];
-        if (!HALF) a0l[s] = reinterpret_cast<const f16x8*>(a.q0l)[q0_rec<NS0>(w, s) * 64 + lane];
-        if (!SH) {
-          cen[2 * s] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h);
-          cen[2 * s + 1] = *reinterpret_cast<const f32x4*>(a.centers + 16 * s + 8 * h + 4);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)  // bias pre-multiplied by 2 log2(e): tanh(z) = 1 - 2 / (exp2(2 log2(e) z) + 1)
-        b0r[q] = *reinterpret_cast<const f32x4*>(a.b0 + 32 * w + 8 * q + 4 * h) * (2.0f * LOG2E);
       float d_n = pdist[min(T0 * 32, last_base) + c32], c_n = pcut[min(T0 * 32, last_base) + c32];
       f16x4 hh[4], hl[4];  // hidden slice of the staged tile, split, 4 features per register group
       float* const frag_b0 = frag_l;                 // DBS: the two fragment buffers ...
@@ -271,12 +303,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         }
       } else {
       const int cw = FS ? 2 * split + w : w;  // feature slice of this wave
-      f16x8 b1h[8], b1l[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        b1h[s] = reinterpret_cast<const f16x8*>(a.q1h)[(cw * 8 + s) * 64 + lane];
-        if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw * 8 + s) * 64 + lane];
-      }
       // Whole-aggregate mode: a row offset o = row * 512 + column carries the aggregate's LDS address as well, so it is
       // the LDS address of the aggregate element as it stands (no add per access: 20 per tile on the consumers' chain,
       // which is the longer one here) and, against a base moved back by the same amount, the offset of the x1 gather.
@@ -398,16 +424,31 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             X.oi[q] = oi_m[q] + col4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.oj[4 * q + e] = oj_m[4 * q + e] + col4;
-            if (FMD_DBG_SKIP(a, 6)) {   // diagnostic build: no row gathers (timing only: what the address path costs)
-              X.xi[q] = 1.0f;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = 0.5f;
-              return;
-            }
             X.xi[q] = *reinterpret_cast<const float*>(x1b + X.oi[q]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
           };
+#ifdef FMD_EXP_HOIST
+          // EXPERIMENT (timing only, wrong sums where rows recur inside a tile): every aggregate row of the tile is read
+          // up front -- what the update would cost if its four LDS round trips did not depend on one another
+          float vj4[16], cv4[4];
+          static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vj4[4 * q + e] = agg_rd(X.oj[4 * q + e]);
+            cv4[q] = agg_rd(X.oi[q]);
+          });
+          static_for<0, 4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vj[e] = vj4[4 * q + e];
+            cval = cv4[q];
+            seg_finish(qc);
+            __builtin_amdgcn_sched_barrier(0);
+            seg_refill(qc);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+#else
           seg_reads(std::integral_constant<int, 0>{});
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -418,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             seg_refill(qc);
             __builtin_amdgcn_sched_barrier(0);
           });
+#endif
         }
         FMD_MARK(0)
         if (DB) fetch_meta(t + S);  // (the list registers are free once X is refilled; there is no B-A window in this form)
@@ -491,7 +533,11 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
     for (int i = tid * 4; i < n * F; i += 2048)
       *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(agg + i);
   }
+  if (queued && tid0 == 0) *next_item_p = (int)atomicAdd(a.queue, 1) + n_wg;   // read behind the next item's first barrier
   }  // work items
+  };  // run
+  if (producer) run(std::true_type{});
+  else run(std::false_type{});
   FMD_STAMP_FLUSH(a, wave)
 }
 

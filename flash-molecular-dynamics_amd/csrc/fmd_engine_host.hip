@@ -102,6 +102,7 @@ struct Workspace {
   int32_t* report;  // [n_mol][3] pairs_kernel -> finish_kernel
   int* items;       // [n_mol * n_split][2][ITEM_INTS] work items of the pair kernels (sched_body)
   int* extra_row;   // [N]
+  int* queue;       // [16] item counters of the pair-kernel launches in queue mode (zeroed by pairs_kernel)
   int64_t total;
 };
 
@@ -175,6 +176,7 @@ Workspace carve_ws(const fmd_schnet_desc* d, void* base, int64_t n_mol, int64_t 
   w.report = (int32_t*)take(n_mol * 12);
   w.items = (int*)take(n_mol * n_split * 2 * ITEM_INTS * 4);
   w.extra_row = (int*)take(n_nodes * 4);
+  w.queue = (int*)take(16 * 4);
   // filter stash (EdgeArgs::wst): one float per list entry and feature, for every block whose backward pass has a gx1
   // aggregate to update (all but the first).  Last in the carve: nothing else moves when it is switched off.
   // fp32-grade precision only: with a third of the MFMA work the W16A16 kernels gain less from the dropped layer than the
@@ -341,7 +343,11 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
   const bool chain = !fs && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
   const int n_slabs = chain ? 2 : split;                       // regular slabs the node kernels add
-  const int64_t pair_wgs = chain ? cus : n_mol;                // grid.y of the pair kernels
+  // queue mode (round 5): more (molecule, split) items than CUs -- e.g. a thousand small molecules -- run as ONE workgroup
+  // per CU that keeps its weight fragments and draws items from a device counter, instead of rounds of one-item
+  // workgroups (static items, no feature split; a caller-given n_split keeps the plain launch)
+  const bool queue = !fs && !chain && desc->n_split == 0 && n_mol * split > cus;
+  const int64_t pair_wgs = chain || queue ? cus : n_mol;       // grid.y of the pair kernels
   if ((int64_t)(n_slabs + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
   const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, n_slabs);
   const PackLayout PL = pack_layout(desc);
@@ -359,7 +365,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     PairsArgs pa;
     pa.pos = pos; pa.mol_ptr = mol_ptr; pa.rc = desc->cutoff; pa.cap = (int)cap; pa.poi = ws.poi; pa.poj = ws.poj;
     pa.pd = ws.pd; pa.pc = ws.pc; pa.pdc = ws.pdc; pa.npairs = ws.npairs; pa.report = ws.report;
-    pa.max_beads = (int)max_beads_per_mol; pa.forces = forces; pa.extra_row = ws.extra_row;
+    pa.max_beads = (int)max_beads_per_mol; pa.forces = forces; pa.extra_row = ws.extra_row; pa.queue = ws.queue;
     // the pair kernels' work items (sched_body in fmd_engine_pairs.hip): balanced when the split is left to the library
     // and the whole launch is one round of workgroups; a caller-given n_split keeps the static tile interleave
     sa.npairs = ws.npairs; sa.mol_ptr = mol_ptr; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
@@ -392,6 +398,10 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ea.gamma = desc->gamma; ea.rc = desc->cutoff; ea.cap = (int)cap; ea.n_split = split;
     ea.pgd_stride = n_mol * cap; ea.fs = fs; ea.max_beads = (int)max_beads_per_mol;
     ea.wst = ws.wst[l];
+    // (launch index: forward block l -> l, backward block l -> L + l; each launch has its own counter)
+    ea.queue = queue ? ws.queue + (fwd ? l : L + l) : nullptr;
+    ea.n_items = (int)(n_mol * split);
+    if (queue) ea.n_split = 1;   // grid (1, CUs): the items carry molecule and split
 #ifdef FMD_PHASE_STAMPS
     ea.stamps = (l == g_stamp_block && (fwd ? 1 : 0) == g_stamp_fwd) ? g_stamps : nullptr;
     ea.dbg = (ea.stamps || g_stamp_block == -2) ? g_stamp_dbg : 0;   // block -2: the switches apply to every launch

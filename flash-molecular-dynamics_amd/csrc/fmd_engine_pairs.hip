@@ -20,7 +20,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
                                                     float* __restrict__ pd, float* __restrict__ pc,
                                                     float* __restrict__ pdc, int32_t* __restrict__ npairs,
                                                     int32_t* __restrict__ report, int max_beads, float* __restrict__ forces, int ent_cap,
-                                                    int* __restrict__ extra_row) {
+                                                    int* __restrict__ extra_row, int* __restrict__ queue) {
   // Two workgroups (16 waves each) per molecule.  Both build the hit masks, counts and offsets of the whole
   // molecule (one wave per centre row, rows dealt round-robin: the row's candidates j > i are tested 64 at a time,
   // the ballots are kept as hit masks in LDS); each then fills and finishes the rows of ITS half of the entries.
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     n = max_beads;
   }
   const bool bad_bound = (int)(mol_ptr[m + 1] - a0) > max_beads;
+  if (m == 0 && part == 0 && tid < 16) queue[tid] = 0;   // the pair kernels' item counters (queue mode) of this evaluation
   float* sx = smem;
   float* sy = sx + n;
   float* sz = sy + n;
@@ -253,8 +254,10 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   int r_next = r_split;  // the first non-empty row of the second part: its (final) offset ends the first part's pads
   while (r_next < n && cnt[r_next] == 0) ++r_next;
   const int k_split = r_next < n ? rowstart[r_next] : total;
-  const int r_lo = part ? r_split : 0, r_hi = part ? n : r_split;
-  const int k_lo = part ? k_split : 0, k_hi = part ? total : k_split;
+  // (small molecules are launched with ONE workgroup per molecule, which then fills every row: launch_pairs)
+  const bool whole = gridDim.x == 1;
+  const int r_lo = part ? r_split : 0, r_hi = (part || whole) ? n : r_split;
+  const int k_lo = part ? k_split : 0, k_hi = (part || whole) ? total : k_split;
   // ---- pass 2: fill from the masks (sorted by j)
   uint32_t* oi_out = poi + (int64_t)m * cap;  // centre row byte offset  i * 512
   uint32_t* oj_out = poj + (int64_t)m * cap;  // neighbour row byte offset j * 512
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   }
   // fill the last 32-entry tile with null entries (row 0, zero cutoff) so the edge kernels never
   // need a validity test
-  if (part == 1) {
+  if (part == 1 || whole) {
     const int tot_c = min(total, cap) & ~7;
     const int tot32 = min((tot_c + 31) & ~31, cap);
     for (int k = tot_c + tid; k < tot32; k += 1024) {
@@ -699,9 +702,13 @@ int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s) {
   const size_t base = (size_t)(7 * nb + 2 + 2 * ((nb + 63) / 64) * nb) * sizeof(float);
   const size_t lds = base + (size_t)a.cap * 4 < LDS_PAIRS_MAX ? base + (size_t)a.cap * 4 : LDS_PAIRS_MAX;
   const int ent_cap = (int)((lds - base) / 4);
-  pairs_kernel<<<dim3(2, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol_ptr, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
+  // Two workgroups per molecule build the masks and offsets redundantly and fill half of the entries each; below ~100
+  // beads the fill is a small part of the kernel and the second workgroup only doubles the launch (1024 molecules of
+  // 35 beads: 70 us with two, see profiles/r05_*small_molecules*)
+  const unsigned parts = a.max_beads <= 96 ? 1u : 2u;
+  pairs_kernel<<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol_ptr, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
                                                            a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
-                                                           a.forces, ent_cap, a.extra_row);
+                                                           a.forces, ent_cap, a.extra_row, a.queue);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
 

@@ -841,6 +841,42 @@ def test_engine_from_state_dict_file(params, golden_dir, tmp_path):
 
 
 @pytest.mark.parametrize("precision", ["f32", "w16a16"])
+def test_queue_mode_many_small_molecules(params, precision):
+    """More (molecule, split) items than CUs -- 700 molecules of 6..60 beads -- run in QUEUE mode (round 5): one
+    workgroup per CU keeps its weight fragments and draws items from a device counter; pairs_kernel uses one workgroup
+    per molecule below 97 beads.  An item's result lands in its own slab rows whoever computes it, so: energies and
+    forces equal the plain one-workgroup-per-item launch (caller-given n_split = 1) bit for bit, repeat calls are
+    bit-identical, and the molecules meet the fp64 oracle."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(5)
+    sizes = torch.randint(6, 61, (700,), generator=g).tolist()
+    parts = [so.synth_batch(1, n, 5.0, first_mol=k) for k, n in enumerate(sizes)]
+    pos = torch.cat([q[0] for q in parts])
+    types = torch.cat([q[1] for q in parts])
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    model = S.model_from_params(params).to(DEV)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    queued = engine.FusedSchNetEngine(model, precision=precision)
+    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=1)
+    e, f = queued.energy_forces(P, T, Q, 60)
+    queued.check_status()
+    e1, f1 = plain.energy_forces(P, T, Q, 60)
+    assert torch.isfinite(f).all() and torch.equal(e, e1) and torch.equal(f, f1)
+    e2, f2 = queued.energy_forces(P, T, Q, 60)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    pick = [0, 1, 255, 256, 257, 511, 512, 698, 699]
+    sel = torch.cat([torch.arange(int(ptr[m]), int(ptr[m + 1])) for m in pick])
+    ptr_s = torch.tensor([0] + list(np.cumsum([sizes[m] for m in pick])), dtype=torch.int64)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sel].double(), types[sel], ptr_s)
+    re, rf = _relerr(e.cpu()[pick], f.cpu()[sel], e_o.numpy(), f_o.numpy())
+    print(f"queue mode, 700 small molecules, {precision}: energy {re:.2e} forces {rf:.2e} vs the fp64 oracle")
+    tol = 5e-3 if precision == "w16a16" else 2e-5
+    assert re < tol and rf < tol
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
 @pytest.mark.parametrize("num_rbf", [65, 100, 128])
 def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
     """Engine envelope, round 5: a Gaussian basis of 65..128 functions (StandardSchNet takes any, reference

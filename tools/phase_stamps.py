@@ -12,7 +12,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "flash-molecular-dynamics_amd")]
 import torch  # noqa: E402
 from flashmd_amd import _ffi  # noqa: E402
 
-_ffi.LIB_PATH = os.path.join(ROOT, "flash-molecular-dynamics_amd", "csrc", "build_stamps", "libflashmd_hip_stamps.so")
+_ffi.LIB_PATH = os.environ.get("FMD_STAMPS_LIB") or os.path.join(ROOT, "flash-molecular-dynamics_amd", "csrc", "build_stamps",
+                                                                  "libflashmd_hip_stamps.so")
 import flashmd_amd.schnet as S  # noqa: E402
 from flashmd_amd import engine, synthetic  # noqa: E402
 
