@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
       if (!HALF) b1l[s] = reinterpret_cast<const f16x8*>(a.q1l)[(cw0 * 8 + s) * 64 + lane0];
     }
   }
-  const bool queued = a.queue != nullptr;   // uniform over the launch
+  const bool queued = !FS && a.queue != nullptr;   // uniform over the launch (the feature-split mode has no queue)
   const int* const wi_base = queued ? a.items : a.items + ((int64_t)m_own * gridDim.x + split) * (2 * ITEM_INTS);
   int q_item = lid_wg;
   for (int it = 0;; ++it) {
