@@ -290,8 +290,8 @@ __device__ __forceinline__ Cols8 gemm8_half(const _Float16* tile, const WFrag8& 
   return c;
 }
 
-// node_out: lin2 -> tanh -> lin -> residual -> output network forward -> its backward from dE/de = 1 -> dE/dx.  Its
-// operands do not all fit the register file, so they are streamed through two fragment sets: the request for operand
+// node_out: lin2 -> tanh -> lin -> residual -> output network forward -> its backward from dE/de = 1 -> dE/dx.  lin2 and
+// lin stay in registers; the output network's operands are streamed through two fragment sets: the request for operand
 // idx + 2 goes out right BEHIND GEMM idx, into the set that GEMM has just read (it then has the whole next stage plus
 // this stage's epilogue to arrive); all requests are unconditional (past the last tile they re-read operands 0 and 1)
 // so that the compiler can count them.  The output network ends in Linear(w, 1) without bias and the backward pass
@@ -302,26 +302,25 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * N8PLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * N8PLANE];
   __shared__ float e_part[2][8][32];  // per-wave partial energies of a tile's rows (double-buffered over tiles)
+  __shared__ __attribute__((aligned(16))) float bias_s[5][128];
   const int tid = threadIdx.x, lane = tid & 63, v = __builtin_amdgcn_readfirstlane(tid >> 6), nl = lane & 15;
   const int64_t n_tiles = (a.n_nodes + 31) / 32;
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
   constexpr int NH = NUM_OUT - 1;      // hidden layers of the output network (tanh, with bias)
-  constexpr int NOPS = 2 + 2 * NH;     // lin2, lin, po[0..NH-1], pot[NH-1..0]
+  constexpr int NOPS = 2 * NH;         // streamed operands: po[0..NH-1], pot[NH-1..0]  (lin2 and lin stay resident)
   const float* ops[NOPS];
-  ops[0] = a.l2;
-  ops[1] = a.l3;
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
-    ops[2 + k] = a.po[k];
-    ops[2 + NH + k] = a.pot[NH - 1 - k];
+    ops[k] = a.po[k];
+    ops[NH + k] = a.pot[NH - 1 - k];
   }
-  WFrag8 fb0, fb1;
-  auto gemm = [&](auto idx_c, const _Float16* t) -> Cols8 {
+  WFrag8 w2r, w3r, fb0, fb1;
+  auto gemm = [&](auto idx_c, const _Float16* t) -> Cols8 {   // streamed operand idx of the output network
     constexpr int idx = decltype(idx_c)::value;
     WFrag8& cur = (idx & 1) ? fb1 : fb0;
     Cols8 r;
-    if constexpr (HOUT && idx >= 2) r = gemm8_half(t, cur, lane);
+    if constexpr (HOUT) r = gemm8_half(t, cur, lane);
     else r = gemm8(t, cur, lane);
     load_wfrag8(cur, ops[(idx + 2) % NOPS], v, lane);  // NOPS is even: the next tile's operands 0, 1 land in fb0, fb1
     return r;
@@ -333,14 +332,23 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
   Rows8 pre;
   rows_fetch8<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, tile * 32, a.n_nodes, tid);
   Cols8 xo = load_cols8(a.x, tile * 32, a.n_nodes, v, lane);
+  load_wfrag8(w2r, a.l2, v, lane);
+  load_wfrag8(w3r, a.l3, v, lane);
   load_wfrag8(fb0, ops[0], v, lane);
-  load_wfrag8(fb1, ops[1], v, lane);
-  const f32x4 b2 = bias8(a.b2, v, lane), b3 = bias8(a.b3, v, lane);
-  f32x4 bo_r[NH];
+  load_wfrag8(fb1, ops[1 % NOPS], v, lane);
+  // Biases and the last layer's weight vector live in LDS (2.5 KB) and are read where they are used: in registers they
+  // cost 20 of the 256 a wave has here (the fp32 three-layer form spilled), and read from global memory inside the tile
+  // loop each 64-byte request would wait for every operand request in flight (the memory counter is in order).
+  if (tid < 128) {
+    bias_s[0][tid] = a.b2[tid];
+    bias_s[1][tid] = a.b3[tid];
 #pragma unroll
-  for (int k = 0; k < NH; ++k) bo_r[k] = bias8(a.bo[k], v, lane);
-  const f32x4 wl = bias8(a.w_last, v, lane);  // the last layer's weight vector, this lane's four columns
+    for (int k = 0; k < NH; ++k) bias_s[2 + k][tid] = a.bo[k][tid];
+    bias_s[4][tid] = a.w_last[tid];
+  }
+  auto bias_rd = [&](int k) { return *reinterpret_cast<const f32x4*>(&bias_s[k][16 * v + 4 * (lane >> 4)]); };
   __builtin_amdgcn_s_waitcnt(0x0F70);  // everything requested so far has landed
+  __syncthreads();
   int par = 0;
   for (; tile < n_tiles; tile += gridDim.x, par ^= 1) {
     const int64_t row0 = tile * 32, next = tile + gridDim.x;
@@ -350,17 +358,23 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
     rows_commit8(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, row0, a.n_nodes, tid);
     const Cols8 x_old = xo;
     lds_barrier();
-    Cols8 acc = gemm(std::integral_constant<int, 0>{}, bufX);
+    Cols8 acc = gemm8(bufX, w2r, lane);
+    {
+      const f32x4 b2 = bias_rd(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) acc.t[t] = tanh4(acc.t[t] + b2);
+      for (int t = 0; t < 2; ++t) acc.t[t] = tanh4(acc.t[t] + b2);
+    }
     store_cols8(a.t_out, row0, v, lane, acc);
     cols_to_planes8(bufY, acc, v, lane);
     lds_barrier();
-    acc = gemm(std::integral_constant<int, 1>{}, bufY);
+    acc = gemm8(bufY, w3r, lane);
+    {
+      const f32x4 b3 = bias_rd(1);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      acc.t[t] = x_old.t[t] + (acc.t[t] + b3);
-      if (!ok[t]) acc.t[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 2; ++t) {
+        acc.t[t] = x_old.t[t] + (acc.t[t] + b3);
+        if (!ok[t]) acc.t[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     put(bufX, acc);
     lds_barrier();
@@ -370,9 +384,12 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
     _Float16* nxt = bufY;
     static_for<0, NH>([&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      hk[k] = gemm(std::integral_constant<int, 2 + k>{}, cur);
+      hk[k] = gemm(std::integral_constant<int, k>{}, cur);
+      {
+        const f32x4 bk = bias_rd(2 + k);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) hk[k].t[t] = tanh4(hk[k].t[t] + bo_r[k]);
+        for (int t = 0; t < 2; ++t) hk[k].t[t] = tanh4(hk[k].t[t] + bk);
+      }
       if constexpr (k + 1 < NH) {
         put(nxt, hk[k]);  // W16A16: hk <- f16(tanh), what the next layer and the backward see
         lds_barrier();
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
     });
     // ---- ... last layer: e = <w_last, h>: this lane's four columns, then the wave's four column groups (lane bits 4, 5);
     //      the eight waves' parts meet in LDS behind the next barrier
+    const f32x4 wl = bias_rd(4);  // the last layer's weight vector, this lane's four columns
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const f32x4& hv = hk[NH - 1].t[t];
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
     }
     static_for<0, NH - 1>([&](auto jc) {
       constexpr int j = decltype(jc)::value;   // operand pot[NH-1-j], then times 1 - hk[NH-2-j]^2
-      g = gemm(std::integral_constant<int, 2 + NH + j>{}, cur);
+      g = gemm(std::integral_constant<int, NH + j>{}, cur);
 #pragma unroll
       for (int t = 0; t < 2; ++t) g.t[t] *= 1.0f - hk[NH - 2 - j].t[t] * hk[NH - 2 - j].t[t];
       put(nxt, g);

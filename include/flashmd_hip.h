@@ -38,7 +38,8 @@ const char* fmd_strerror(int code);
  *   4: fmd_schnet_desc ends in `flags`.
  *   5: the only flag is FMD_FLAG_NO_FILTER_STASH (the opt-in tabulated-filter prototype of ABI 4, bit 2, left the
  *      product: measured at 0.63x of the MFMA path, DESIGN.md section 3 "Round 4"); desc.cutoff must be finite and
- *      > 0, desc.gamma finite, else FMD_EINVAL. */
+ *      > 0, desc.gamma finite, else FMD_EINVAL; num_rbf up to 128; fmd_overdamped_step; the packed weight layout
+ *      changed (fmd_schnet_pack_bytes says how much). */
 int fmd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -170,7 +171,7 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
  * (models/gradients.py:226-290) for StandardSchNet models (Gaussian basis, cosine cutoff with
  * lower bound 0, tanh).  The kernels are built for hidden = filters = 128: the caller passes weights zero-padded to
  * that width (narrower layers are exact under zero padding: a padded feature is 0 in every layer; the Python host
- * pads hidden, filters <= 128 by itself) and 2 <= num_rbf <= 64.
+ * pads hidden, filters <= 128 by itself) and 2 <= num_rbf <= 128 (65..128: molecules of at most 283 beads, ABI 5).
  *   Weights are packed once by fmd_schnet_pack_bytes / fmd_schnet_pack (device buffer).
  *   precision: FMD_PREC_F32 (default: every operand of the filter-network contractions is carried as two fp16
  *   words, a.b = hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- relative error 2e-7,
@@ -187,7 +188,7 @@ int fmd_matmul_f32_f16_to_f16(const float* a, const void* b, void* c, int64_t m,
 
 typedef struct fmd_schnet_desc {
   int32_t hidden;        /* = num_filters = 128: the kernels' width (narrower models: zero-padded weights, see above) */
-  int32_t num_rbf;       /* R (<= 64) */
+  int32_t num_rbf;       /* R (<= 128; beyond 64 the feature-split mode for molecules above 283 beads is not available) */
   int32_t num_blocks;    /* L */
   int32_t num_out;       /* number of output-network linears (2 or 3) */
   int32_t out_width[4];  /* widths after each output linear, last = 1 */
