@@ -142,6 +142,8 @@ struct NodeOutArgs {
   const float* w_last;  // [128] the last layer's weight vector (Linear(w, 1), no bias), zero beyond its width
   float* e_node;        // [N]
   float* gx;            // [N,128] dE/dx_L
+  const float *l3t, *l2t;  // the last block's lin / lin2, transposed operands: its node backward is fused into node_out
+  float* gagg;          // [N,128] dE/d(agg) of the last block
   int64_t n_nodes;
 };
 
@@ -215,7 +217,7 @@ int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x
                       int64_t n_nodes, const SchedArgs& sa, hipStream_t s);
 int launch_node_fwd(const NodeFwdArgs& a, unsigned grid, hipStream_t s);
 int launch_node_out(const NodeOutArgs& a, int num_out, bool hout, unsigned grid, hipStream_t s);
-int launch_node_bwd(const NodeBwdArgs& a, bool has_slabs, unsigned grid, hipStream_t s);
+int launch_node_bwd(const NodeBwdArgs& a, unsigned grid, hipStream_t s);
 
 }  // namespace fmd_eng
 

@@ -443,6 +443,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     }
     oa.w_last = pk + PL.outs + (desc->num_out - 1) * PL.out_stride + SLICE;
     oa.e_node = ws.e_node; oa.gx = ws.gx; oa.n_nodes = n_nodes;
+    oa.l3t = pk + q.l3t; oa.l2t = pk + q.l2t; oa.gagg = ws.gagg;   // the last block's node backward rides along
     ev_begin();
     rc = launch_node_out(oa, desc->num_out, half, res_grid, s);
     ev_end();
@@ -455,10 +456,12 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     ba.gx = ws.gx; ba.slabs = ws.slabs; ba.slab_stride = slab_stride; ba.n_slabs = n_slabs; ba.extra_row = ws.extra_row;
     ba.t = ws.t[l]; ba.l3t = pk + o.l3t; ba.l2t = pk + o.l2t; ba.gagg = ws.gagg; ba.n_nodes = n_nodes;
     ba.l1t = l == L - 1 ? nullptr : pk + block_off(PL, l + 1).l1t;
-    ev_begin();
-    rc = launch_node_bwd(ba, /*has_slabs=*/l != L - 1, res_grid, s);
-    ev_end();
-    if (rc != FMD_OK) return rc;
+    if (l != L - 1) {   // (the last block's node backward is part of node_out)
+      ev_begin();
+      rc = launch_node_bwd(ba, res_grid, s);
+      ev_end();
+      if (rc != FMD_OK) return rc;
+    }
     ev_begin();
     rc = edge(false, l);
     ev_end();
@@ -489,16 +492,18 @@ extern "C" int fmd_schnet_energy_forces(const fmd_schnet_desc* desc, const void*
 }
 
 extern "C" int fmd_schnet_kernel_count(const fmd_schnet_desc* desc) {
-  return desc_ok(desc) ? 4 * desc->num_blocks + 3 : FMD_EINVAL;
+  return desc_ok(desc) ? 4 * desc->num_blocks + 2 : FMD_EINVAL;
 }
 
 extern "C" const char* fmd_schnet_kernel_name(const fmd_schnet_desc* desc, int idx) {
-  if (!desc_ok(desc) || idx < 0 || idx >= 4 * desc->num_blocks + 3) return "";
+  if (!desc_ok(desc) || idx < 0 || idx >= 4 * desc->num_blocks + 2) return "";
   const int L = desc->num_blocks;
+  // pairs | [node_fwd, edge_fwd] x L | node_out (with the last block's node backward) | edge_bwd | [node_bwd, edge_bwd]
+  // x (L - 1) | finish
   if (idx == 0) return "pairs_kernel";
   if (idx <= 2 * L) return (idx & 1) ? "node_fwd_kernel" : "edge_fwd_kernel";
   if (idx == 2 * L + 1) return "node_out_kernel";
-  if (idx <= 4 * L + 1) return (idx & 1) ? "edge_bwd_kernel" : "node_bwd_kernel";
+  if (idx <= 4 * L) return (idx & 1) ? "node_bwd_kernel" : "edge_bwd_kernel";
   return "finish_kernel";
 }
 
@@ -509,7 +514,7 @@ extern "C" int fmd_schnet_energy_forces_timed(const fmd_schnet_desc* desc, const
                                               float* energy, float* forces, void* workspace,
                                               int32_t* status, void* stream, void** events,
                                               int64_t n_events) {
-  if (!desc_ok(desc) || !events || n_events < 2 * (4 * desc->num_blocks + 3)) return FMD_EINVAL;
+  if (!desc_ok(desc) || !events || n_events < 2 * (4 * desc->num_blocks + 2)) return FMD_EINVAL;
   return run_engine(desc, packed_dev, pos, atom_types, mol_ptr, n_mol, n_nodes, max_beads_per_mol,
                     max_pairs_per_mol, energy, forces, workspace, status, stream,
                     reinterpret_cast<hipEvent_t*>(events));

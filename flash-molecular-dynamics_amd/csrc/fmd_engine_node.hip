@@ -201,7 +201,8 @@ __global__ __launch_bounds__(512) void node_fwd8_kernel(NodeFwdArgs a) {
   }
 }
 
-template <bool HAS_SLABS>
+// node backward of blocks L-2 .. 0 (the last block's runs inside node_out8_kernel): gx += (sum of gx1 partials) lin1 of
+// the block above, then dE/d agg = ((gx lin) (1 - t^2)) lin2
 __global__ __launch_bounds__(512) void node_bwd8_kernel(NodeBwdArgs a) {
   __shared__ __attribute__((aligned(16))) _Float16 bufX[2 * N8PLANE];
   __shared__ __attribute__((aligned(16))) _Float16 bufY[2 * N8PLANE];
@@ -215,38 +216,25 @@ __global__ __launch_bounds__(512) void node_bwd8_kernel(NodeBwdArgs a) {
   Cols8 t_nx, gx_nx;
   auto fetch = [&](int64_t t) {
     t_nx = load_cols8(a.t, t * 32, a.n_nodes, v, lane);
-    if (HAS_SLABS) {
-      gx_nx = load_cols8(a.gx, t * 32, a.n_nodes, v, lane);
-      rows_fetch8<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, t * 32, a.n_nodes, tid);
-    } else {
-      rows_fetch8<false>(pre, a.gx, 0, 1, nullptr, t * 32, a.n_nodes, tid);
-    }
+    gx_nx = load_cols8(a.gx, t * 32, a.n_nodes, v, lane);
+    rows_fetch8<true>(pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, t * 32, a.n_nodes, tid);
   };
   fetch(tile);
-  if (HAS_SLABS) load_wfrag8(w1, a.l1t, v, lane);
+  load_wfrag8(w1, a.l1t, v, lane);
   load_wfrag8(w3, a.l3t, v, lane);
   load_wfrag8(w2, a.l2t, v, lane);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // operands landed before the loop (see node_fwd8_kernel)
   for (; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * 32, next = tile + gridDim.x;
-    const Cols8 t_pre = t_nx;
-    Cols8 gx_pre;
-    if (HAS_SLABS) {
-      gx_pre = gx_nx;
-      rows_commit8(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, row0, a.n_nodes, tid);
-    } else {
-      rows_commit8(bufY, pre, a.gx, 0, 1, nullptr, row0, a.n_nodes, tid);
-    }
+    const Cols8 t_pre = t_nx, gx_pre = gx_nx;
+    rows_commit8(bufX, pre, a.slabs, a.slab_stride, a.n_slabs, a.extra_row, row0, a.n_nodes, tid);
     fetch(next < n_tiles ? next : n_tiles - 1);  // (past the last tile: the last tile again, unused)
-    Cols8 acc;
-    if (HAS_SLABS) {  // gx += (sum of gx1 partials) lin1
-      lds_barrier();
-      acc = gemm8(bufX, w1, lane);
+    lds_barrier();
+    Cols8 acc = gemm8(bufX, w1, lane);  // gx += (sum of gx1 partials) lin1
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc.t[t] = gx_pre.t[t] + acc.t[t];
-      store_cols8(a.gx, row0, v, lane, acc);
-      cols_to_planes8(bufY, acc, v, lane);
-    }
+    for (int t = 0; t < 2; ++t) acc.t[t] = gx_pre.t[t] + acc.t[t];
+    store_cols8(a.gx, row0, v, lane, acc);
+    cols_to_planes8(bufY, acc, v, lane);
     lds_barrier();
     acc = gemm8(bufY, w3, lane);  // d/d tanh(conv) = gx lin
 #pragma unroll
@@ -255,10 +243,8 @@ __global__ __launch_bounds__(512) void node_bwd8_kernel(NodeBwdArgs a) {
     lds_barrier();
     acc = gemm8(bufZ, w2, lane);  // d/d agg = gconv lin2
     store_cols8(a.gagg, row0, v, lane, acc);
-    if (!HAS_SLABS) lds_barrier();  // bufY is refilled at the top of the next tile
   }
 }
-
 
 // W16A16 output network, eight-wave form: one fp16 plane (round to nearest even; the value later layers and the backward
 // see is written back to c); its GEMMs are one MFMA per k-step against the hi record (= Linear.weight.half())
@@ -308,19 +294,22 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
   int64_t tile = blockIdx.x;
   if (tile >= n_tiles) return;
   constexpr int NH = NUM_OUT - 1;      // hidden layers of the output network (tanh, with bias)
-  constexpr int NOPS = 2 * NH;         // streamed operands: po[0..NH-1], pot[NH-1..0]  (lin2 and lin stay resident)
+  // streamed operands: po[0..NH-1], pot[NH-1..0], then lin^T and lin2^T of the last block (lin2 and lin stay resident)
+  constexpr int NOPS = 2 * NH + 2;
   const float* ops[NOPS];
 #pragma unroll
   for (int k = 0; k < NH; ++k) {
     ops[k] = a.po[k];
     ops[NH + k] = a.pot[NH - 1 - k];
   }
+  ops[2 * NH] = a.l3t;
+  ops[2 * NH + 1] = a.l2t;
   WFrag8 w2r, w3r, fb0, fb1;
-  auto gemm = [&](auto idx_c, const _Float16* t) -> Cols8 {   // streamed operand idx of the output network
+  auto gemm = [&](auto idx_c, const _Float16* t) -> Cols8 {   // streamed operand idx
     constexpr int idx = decltype(idx_c)::value;
     WFrag8& cur = (idx & 1) ? fb1 : fb0;
     Cols8 r;
-    if constexpr (HOUT) r = gemm8_half(t, cur, lane);
+    if constexpr (HOUT && idx < 2 * NH) r = gemm8_half(t, cur, lane);   // (the node linears stay fp32-grade in W16A16)
     else r = gemm8(t, cur, lane);
     load_wfrag8(cur, ops[(idx + 2) % NOPS], v, lane);  // NOPS is even: the next tile's operands 0, 1 land in fb0, fb1
     return r;
@@ -365,6 +354,7 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
       for (int t = 0; t < 2; ++t) acc.t[t] = tanh4(acc.t[t] + b2);
     }
     store_cols8(a.t_out, row0, v, lane, acc);
+    const Cols8 t_keep = acc;   // tanh(conv) of the last block: its node backward runs at the end of this chain
     cols_to_planes8(bufY, acc, v, lane);
     lds_barrier();
     acc = gemm8(bufY, w3r, lane);
@@ -441,8 +431,19 @@ __global__ __launch_bounds__(512) void node_out8_kernel(NodeOutArgs a) {
       lds_barrier();
       _Float16* tmp = cur; cur = nxt; nxt = tmp;
     });
-    g = gemm(std::integral_constant<int, NOPS - 1>{}, cur);
+    g = gemm(std::integral_constant<int, 2 * NH - 1>{}, cur);
     store_cols8(a.gx, row0, v, lane, g);
+    // ---- the LAST block's node backward, fused here (round 5; it was a launch of its own that read gx and t back):
+    //      dE/d agg = ((dE/dx lin) (1 - t^2)) lin2 -- the same values, splits and MFMA order as node_bwd8_kernel
+    cols_to_planes8(nxt, g, v, lane);
+    lds_barrier();
+    g = gemm(std::integral_constant<int, 2 * NH>{}, nxt);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) g.t[t] *= 1.0f - t_keep.t[t] * t_keep.t[t];
+    cols_to_planes8(cur, g, v, lane);
+    lds_barrier();
+    g = gemm(std::integral_constant<int, 2 * NH + 1>{}, cur);
+    store_cols8(a.gagg, row0, v, lane, g);
     lds_barrier();
   }
 }
@@ -462,9 +463,8 @@ int launch_node_out(const NodeOutArgs& a, int num_out, bool hout, unsigned grid,
   else node_out8_kernel<2, false><<<grid, 512, 0, s>>>(a);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
-int launch_node_bwd(const NodeBwdArgs& a, bool has_slabs, unsigned grid, hipStream_t s) {
-  if (has_slabs) node_bwd8_kernel<true><<<grid, 512, 0, s>>>(a);
-  else node_bwd8_kernel<false><<<grid, 512, 0, s>>>(a);
+int launch_node_bwd(const NodeBwdArgs& a, unsigned grid, hipStream_t s) {
+  node_bwd8_kernel<<<grid, 512, 0, s>>>(a);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
 

@@ -1,4 +1,4 @@
-"""Fused whole-path engine: energy[B] and forces[N,3] of a batch in one HIP pipeline of 15 launches
+"""Fused whole-path engine: energy[B] and forces[N,3] of a batch in one HIP pipeline of 14 launches
 (csrc/fmd_engine_{pairs,edge_fwd,edge_bwd,node,host}.hip behind fmd_schnet_energy_forces).
 
 Replaces, for qualifying models, what the reference does per timestep in SchNet.forward +

@@ -974,7 +974,7 @@ def test_w16a16_engine_has_no_filter_stash(params):
 
 @pytest.mark.parametrize("precision,steps_per_graph", [("f32", 1), ("f32", 3), ("w16a16", 1)])
 def test_captured_timestep_is_bit_identical(params, precision, steps_per_graph):
-    """LangevinSimulation.capture(): noise draw + BAOAB halves + the engine's 15 launches as ONE hipGraph (this build's
+    """LangevinSimulation.capture(): noise draw + BAOAB halves + the engine's 14 launches as ONE hipGraph (this build's
     counterpart of the reference's torch.compile wrapper, simulation/base.py:357-368).  Twelve replayed timesteps must
     equal twelve un-captured ones bit for bit -- positions, velocities, forces, energies -- through the
     reference-shaped entry GradientsOut(model)(batch), and the device status must still be readable afterwards."""
