@@ -130,14 +130,18 @@ class LangevinSimulation:
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
             for _ in range(steps_per_graph):
-                self.noise.normal_(generator=self.rng)
-                langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt, self.friction)
-                e, f = self.force_fn(self.x)
-                self.energy.copy_(e)
-                self.f.copy_(f)
-                langevin_post(self.v, self.f, self.masses, self.dt)
+                self._captured_step()
         self._graph, self._graph_steps = g, steps_per_graph
         return self
+
+    def _captured_step(self):
+        """one timestep as it is recorded into the graph: forces and energies go to their fixed buffers"""
+        self.noise.normal_(generator=self.rng)
+        langevin_pre(self.x, self.v, self.f, self.masses, self.beta_node, self.noise, self.dt, self.friction)
+        e, f = self.force_fn(self.x)
+        self.energy.copy_(e)
+        self.f.copy_(f)
+        langevin_post(self.v, self.f, self.masses, self.dt)
 
     def release_graph(self):
         """back to the un-captured loop (e.g. before the batch layout or the force providers change)"""
@@ -396,7 +400,17 @@ class NVESimulation(LangevinSimulation):
     """Microcanonical velocity-Verlet loop (reference simulation/velocity_verlet.py:12-62): same state,
     start-up (Maxwell-Boltzmann velocities) and throughput loop as the Langevin class."""
 
+    def _captured_step(self):
+        verlet_pre(self.x, self.v, self.f, self.masses, self.dt)
+        e, f = self.force_fn(self.x)
+        self.energy.copy_(e)
+        self.f.copy_(f)
+        langevin_post(self.v, self.f, self.masses, self.dt)
+
     def timestep(self):
+        if self._graph is not None:
+            self._graph.replay()
+            return
         if self.use_hip:
             verlet_pre(self.x, self.v, self.f, self.masses, self.dt)
             self.energy, self.f = self.force_fn(self.x)
@@ -422,10 +436,17 @@ class OverdampedSimulation(LangevinSimulation):
                          friction=friction, seed=seed, use_hip=use_hip)
         self.v.zero_()
 
-    def capture(self, steps_per_graph: int = 1, warmup: int = 2):
-        raise NotImplementedError("capture() records the BAOAB kernels; the overdamped loop runs un-captured")
+    def _captured_step(self):
+        self.noise.normal_(generator=self.rng)
+        overdamped_step(self.x, self.f, self.beta_node, self.noise, self.dt, self.friction)
+        e, f = self.force_fn(self.x)
+        self.energy.copy_(e)
+        self.f.copy_(f)
 
     def timestep(self):
+        if self._graph is not None:
+            self._graph.replay()
+            return
         self.draw_noise()
         if self.use_hip:
             overdamped_step(self.x, self.f, self.beta_node, self.noise, self.dt, self.friction)

@@ -874,6 +874,17 @@ def test_queue_mode_many_small_molecules(params, precision):
     print(f"queue mode, 700 small molecules, {precision}: energy {re:.2e} forces {rf:.2e} vs the fp64 oracle")
     tol = 5e-3 if precision == "w16a16" else 2e-5
     assert re < tol and rf < tol
+    # ... and under hipGraph capture: the item counters are zeroed by pairs_kernel INSIDE the captured evaluation, so every
+    # replay starts its queues afresh
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        e_g, f_g = queued.energy_forces(P, T, Q, 60)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    queued.check_status()
+    assert torch.equal(e_g, e) and torch.equal(f_g, f)
 
 
 @pytest.mark.parametrize("precision", ["f32", "w16a16"])
@@ -1052,3 +1063,32 @@ def test_local_replica_exchange_moves_forces_with_the_configurations(params):
         assert torch.equal(sim.f, f_chk) and torch.equal(sim.energy, e_chk)
     m = ex.acceptance_matrix
     assert moved >= 1 and int(m.sum()) == n_indep * (3 * 2 + 3 * 1)   # (0,1),(2,3) x 3 even; (1,2) x 3 odd attempts
+
+
+@pytest.mark.parametrize("kind", ["nve", "overdamped"])
+def test_captured_timestep_of_the_other_integrators(params, kind):
+    """capture() for the velocity-Verlet and the overdamped loop (round 5): eight replayed steps equal eight un-captured
+    ones bit for bit."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine, simulate
+
+    pos, types, ptr = so.synth_batch(6, 41, 5.0)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    eng = engine.FusedSchNetEngine(S.model_from_params(params).to(DEV))
+    beta = torch.full((6,), 1.67, device=DEV)
+
+    def make():
+        fn = lambda x: eng.energy_forces(x, T, Q, 41)  # noqa: E731
+        if kind == "nve":
+            return simulate.NVESimulation(fn, P, torch.full((P.shape[0],), 12.0, device=DEV), beta, 41, dt=0.002, seed=9)
+        return simulate.OverdampedSimulation(fn, P, beta, 41, dt=0.0005, friction=2.0, seed=9)
+
+    eager, graph = make(), make()
+    graph.capture()
+    for _ in range(8):
+        eager.timestep()
+        graph.timestep()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eager.x).all() and float((eager.x - P).abs().max()) > 0
+    assert torch.equal(eager.x, graph.x) and torch.equal(eager.v, graph.v)
+    assert torch.equal(eager.f, graph.f) and torch.equal(eager.energy, graph.energy)
