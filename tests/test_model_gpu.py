@@ -853,6 +853,13 @@ def test_queue_mode_many_small_molecules(params, precision):
     g = torch.Generator().manual_seed(5)
     sizes = torch.randint(6, 61, (700,), generator=g).tolist()
     parts = [so.synth_batch(1, n, 5.0, first_mol=k) for k, n in enumerate(sizes)]
+    # ... among them molecules WITHOUT any pair (a single bead; two beads 50 apart): items with no tile at all
+    for k in (3, 300, 699):
+        sizes[k] = 1
+        parts[k] = (torch.zeros(1, 3), parts[k][1][:1], None)
+    for k in (4, 301):
+        sizes[k] = 2
+        parts[k] = (torch.tensor([[0.0, 0, 0], [50.0, 0, 0]]), parts[k][1][:2], None)
     pos = torch.cat([q[0] for q in parts])
     types = torch.cat([q[1] for q in parts])
     ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
