@@ -702,6 +702,7 @@ def main():
                             "avg_launch_ms": d16, "launches_per_step": lg.launches[lg.dom],
                             **limiter_fields(st16, d16)},
                "timed_regions_ms_per_step": [round(v, 5) for v in m16["regions_ms"]],
+               "smi": m16["smi"],   # (this leg runs near the maximum clock; the fp32 regions at the socket's power cap)
                "dominant_kernel_ms_per_region": [round(v, 5) for v in m16["dom_ms"]],
                "kernel_ms_per_launch": {n: round(v, 4) for n, v in raw16.items()},
                "kernel_ms_per_step": {n: round(v, 4) for n, v in per16.items()}}
