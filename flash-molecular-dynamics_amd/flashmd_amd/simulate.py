@@ -245,11 +245,18 @@ class TrajectoryWriter:
     initial one, or NaN) is evaluated on the device per saved frame and read at export time."""
 
     def __init__(self, filename: str, sim, save_interval: int, export_interval: int, save_forces: bool = False,
-                 save_energies: bool = False, create_checkpoints: bool = False, log_interval: int = 0):
+                 save_energies: bool = False, create_checkpoints: bool = False, log_interval: int = 0, exchange=None,
+                 write_acceptance: bool = True):
+        """``exchange``: a Local- / DistributedReplicaExchange whose acceptance matrix is exported with every chunk as
+        ``{filename}_acceptance_XXXX.npy`` (float32 [n_betas, n_betas], accepted above the diagonal, rejected below) and
+        reset, as the reference's ``save_exchanges`` does (simulation/parallel_tempering.py:504-517).  With one beta per
+        rank the matrix is summed over the ranks at export (a collective: every rank's writer must export at the same
+        step); ``write_acceptance=False`` on all ranks but one keeps a single file."""
         assert export_interval % save_interval == 0 and export_interval >= save_interval
         self.filename, self.save_interval, self.export_interval = filename, save_interval, export_interval
         self.save_forces, self.save_energies, self.create_checkpoints = save_forces, save_energies, create_checkpoints
         self.log_interval = log_interval
+        self.exchange, self.write_acceptance = exchange, write_acceptance
         self.frames = export_interval // save_interval
         dev, n_sims, n_atoms = sim.x.device, sim.n_sims, sim.n_atoms
         self.coords = torch.zeros(self.frames, n_sims, n_atoms, 3, device=dev)
@@ -315,6 +322,12 @@ class TrajectoryWriter:
             ck = None if ck is None else {n_: v_.clone() for n_, v_ in ck.items()}
             flag = self.diverged.clone()
         index = self.index
+        acceptance = None
+        if self.exchange is not None:   # exported BEFORE this step's exchange attempt, then reset (reference order:
+            m = self.exchange.acceptance_matrix   # simulation/base.py:596-615)
+            m = m() if callable(m) else m
+            acceptance = m.detach().to(torch.float32).cpu().numpy().copy()
+            self.exchange.reset_acceptance()
 
         def work():
             if event is not None:
@@ -325,6 +338,12 @@ class TrajectoryWriter:
             for name, arr in host.items():
                 path = f"{self.filename}_{name}_{key}.npy"
                 np.save(path, arr.numpy())
+                self.files.append(path)
+            if acceptance is not None and self.write_acceptance:
+                # (the reference names this file with the chunk counter AFTER write() has advanced it: the matrix of
+                # chunk 0000 is {filename}_acceptance_0001.npy -- simulation/base.py:1453 runs before save_exchanges)
+                path = f"{self.filename}_acceptance_{index + 1:04d}.npy"
+                np.save(path, acceptance)
                 self.files.append(path)
             if ck is not None:
                 ck.update(current_timestep=index + 1, export_interval=self.export_interval,

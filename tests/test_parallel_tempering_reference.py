@@ -131,6 +131,28 @@ def test_local_exchange_torch_path_reproduces_the_reference_pt_run(run):
     assert int(torch.triu(exported + ex.acceptance_matrix, 1).sum()) == int(run["att_approved"].sum())
 
 
+def test_acceptance_file_matches_the_reference_export(run, tmp_path):
+    """The reference's PTSimulation writes ``{filename}_acceptance_XXXX.npy`` at every export and resets the matrix
+    (parallel_tempering.py:504-517), BEFORE that step's exchange attempt (simulation/base.py:596-615).  The same run
+    driven through LangevinSimulation.simulate() with a TrajectoryWriter that knows the exchange: same file name, dtype,
+    shape and counts as the file the reference wrote."""
+    from flashmd_amd import simulate
+
+    n_indep, A, interval = int(run["n_indep"]), int(run["n_atoms"]), int(run["exchange_interval"])
+    sim = _replay_sim(run, "cpu", False)
+    ex = simulate.LocalReplicaExchange(run["betas"].tolist(), n_indep, A, seed=None, rand_source=_uniforms_of(run))
+    n_steps = run["pos"].shape[0]
+    wr = simulate.TrajectoryWriter(str(tmp_path / "pt"), sim, save_interval=1, export_interval=n_steps, exchange=ex)
+    sim.simulate(n_steps, subroutine=ex, interval=interval, writer=wr)
+    name = str(run["acceptance_file_name"])
+    assert [os.path.basename(f) for f in wr.files if "_acceptance_" in os.path.basename(f)] == [name]   # (pt_acceptance_0001.npy)
+    mine = np.load(str(tmp_path / name))
+    assert mine.dtype == run["acceptance_file"].dtype and mine.shape == run["acceptance_file"].shape
+    assert np.array_equal(mine, run["acceptance_file"])
+    # what was counted after the export (the last attempt) is what the reference's matrix held at the end
+    assert np.array_equal(ex.acceptance_matrix.numpy(), run["att_matrix"][-1].astype(np.int64))
+
+
 def test_moved_forces_mode_is_not_the_reference_trajectory(run):
     """The switch matters: with forces travelling with the configurations the step after the first accepted exchange
     already differs from the reference's state (by the half-kick of the force difference), while every proposal and the
