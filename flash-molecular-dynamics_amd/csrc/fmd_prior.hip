@@ -4,6 +4,9 @@
 //   angles     prior/harmonic.py:228-262              U = k (cos(theta) - x0)^2
 //   repulsion  prior/repulsion.py:80-122              U = (sigma / d)^6
 //   dihedrals  prior/fourier_series.py:97-192         U = v0 + sum_n k1_n sin(n phi) + k2_n cos(n phi)
+//   impropers  prior/harmonic.py:301-322 (Harmonic.compute :116-118 on compute_torsions)   U = k (phi - x0)^2
+//   quartic angles     prior/polynomial.py:127-186    U = v0 + sum_n k_n cos(theta)^n
+//   restricted angles  prior/restricted_bending.py:200-238   U = a c^4 + b c^3 + c c^2 + d c + k / sin(theta)^2 + v0, c = cos(theta)
 // with the features of geometry/internal_coordinates.py:72-223.  Energy and the analytic -dU/dpos are added to
 // energy[B] / forces[N,3] in one pass, as a GATHER over the fixed topology: one workgroup per molecule keeps the
 // molecule's positions in LDS, one wave per bead walks that bead's (term, slot) entries (a CSR built once on the
@@ -27,7 +30,8 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 
 // WAVE_PER_BEAD: lanes of a wave share one bead's entries (long lists: the repulsion pairs); otherwise one lane
 // per bead walks its own few entries (bonded terms: <= 2..4 entries per bead) and the whole molecule is one pass.
-template <int KIND, bool WAVE_PER_BEAD>  // 0 bonds, 1 angles (cos), 2 repulsion, 3 dihedrals
+// 0 bonds, 1 angles (cos), 2 repulsion, 3 dihedrals, 4 impropers, 5 quartic angles, 6 restricted angles
+template <int KIND, bool WAVE_PER_BEAD>
 __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ pos,
                                                      const int64_t* __restrict__ mol_ptr,
                                                      const int64_t* __restrict__ mapping,
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ entries, int64_t n_terms,
                                                      float* __restrict__ energy, float* __restrict__ forces,
                                                      int32_t* __restrict__ status, int max_beads) {
-  constexpr int ORDER = KIND == 0 || KIND == 2 ? 2 : (KIND == 1 ? 3 : 4);
+  constexpr int ORDER = KIND == 0 || KIND == 2 ? 2 : (KIND == 3 || KIND == 4 ? 4 : 3);
   extern __shared__ __attribute__((aligned(16))) float sp[];  // [3n] positions of the molecule
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
@@ -84,13 +88,32 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
         }
         gs[1] = (de / d) * r;
         gs[0] = -1.0f * gs[1];
-      } else if (KIND == 1) {
+      } else if (ORDER == 3) {
         const V3 r1 = P(idx[0]) - P(idx[1]), r2 = P(idx[2]) - P(idx[1]);
         const float n1 = sqrtf(dot(r1, r1)), n2 = sqrtf(dot(r2, r2)), inv = 1.0f / (n1 * n2);
         const float c = dot(r1, r2) * inv;
-        const float k = params[t], x0 = params[n_terms + t];
-        u = k * (c - x0) * (c - x0);
-        const float de = 2.0f * k * (c - x0);  // dU/dcos
+        float de;  // dU/dcos
+        if (KIND == 1) {
+          const float k = params[t], x0 = params[n_terms + t];
+          u = k * (c - x0) * (c - x0);
+          de = 2.0f * k * (c - x0);
+        } else if (KIND == 5) {  // rows: v0, k_1 .. k_n (Polynomial.compute, prior/polynomial.py:127-146)
+          u = 0.f;
+          de = 0.f;
+          for (int q2 = n_params - 1; q2 >= 1; --q2) {  // Horner, and the derivative alongside
+            const float kq = params[(int64_t)q2 * n_terms + t];
+            de = de * c + (u + kq);
+            u = (u + kq) * c;
+          }
+          u += params[t];
+        } else {  // rows: a, b, c, d, k, v0; theta = atan2(|r1 x r2|, r1 . r2) => sin^2 = |r1 x r2|^2 / (n1 n2)^2
+          const float pa = params[t], pb = params[n_terms + t], pc = params[2 * n_terms + t];
+          const float pd = params[3 * n_terms + t], pk = params[4 * n_terms + t], v0 = params[5 * n_terms + t];
+          const V3 nx = cross(r1, r2);
+          const float is2 = 1.0f / (dot(nx, nx) * inv * inv);  // 1 / sin^2
+          u = (((pa * c + pb) * c + pc) * c + pd) * c + pk * is2 + v0;
+          de = ((4.0f * pa * c + 3.0f * pb) * c + 2.0f * pc) * c + pd + 2.0f * pk * c * is2 * is2;
+        }
         gs[0] = de * (inv * r2 - (c / (n1 * n1)) * r1);
         gs[2] = de * (inv * r1 - (c / (n2 * n2)) * r2);
         gs[1] = -1.0f * (gs[0] + gs[2]);
@@ -101,15 +124,22 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
         const V3 u1 = rsqrtf(dot(b1, b1)) * b1, u2 = rsqrtf(dot(b2, b2)) * b2, u3 = rsqrtf(dot(b3, b3)) * b3;
         const V3 n1 = cross(u1, u2), n2 = cross(u2, u3), m1 = cross(n1, u2);
         const float phi = atan2f(-dot(m1, n2), dot(n1, n2));
-        const int n_deg = (n_params - 1) / 2;
-        float du = 0.f;  // dU/dphi
-        u = params[t];
-        for (int k = 1; k <= n_deg; ++k) {
-          float sn, cs;
-          sincosf((float)k * phi, &sn, &cs);
-          const float k1 = params[(int64_t)k * n_terms + t], k2 = params[(int64_t)(n_deg + k) * n_terms + t];
-          u += k1 * sn + k2 * cs;
-          du += (float)k * (k1 * cs - k2 * sn);
+        float du;  // dU/dphi
+        if (KIND == 4) {
+          const float k = params[t], x0 = params[n_terms + t];
+          u = k * (phi - x0) * (phi - x0);
+          du = 2.0f * k * (phi - x0);
+        } else {
+          const int n_deg = (n_params - 1) / 2;
+          du = 0.f;
+          u = params[t];
+          for (int k = 1; k <= n_deg; ++k) {
+            float sn, cs;
+            sincosf((float)k * phi, &sn, &cs);
+            const float k1 = params[(int64_t)k * n_terms + t], k2 = params[(int64_t)(n_deg + k) * n_terms + t];
+            u += k1 * sn + k2 * cs;
+            du += (float)k * (k1 * cs - k2 * sn);
+          }
         }
         // dphi/dr with F = ri - rj, G = rj - rk, H = rl - rk, A = F x G, B = H x G
         const V3 Fv = ri - rj, Gv = rj - rk, Hv = rl - rk;
@@ -259,13 +289,13 @@ extern "C" int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr,
                                        const float* params, int n_params, const int64_t* bead_ptr,
                                        const int32_t* entries, int64_t n_terms, float* energy, float* forces,
                                        int32_t* status, void* stream) {
-  if (n_mol < 0 || n_terms < 0 || max_beads_per_mol < 1 || kind < 0 || kind > 3) return FMD_EINVAL;
+  if (n_mol < 0 || n_terms < 0 || max_beads_per_mol < 1 || kind < 0 || kind > 6) return FMD_EINVAL;
   if (n_mol == 0 || n_terms == 0) return FMD_OK;
   if (n_terms >= ((int64_t)1 << 29)) return FMD_EUNSUPPORTED;  // entries pack (term << 2 | slot) in 32 bits
   if (!pos || !mol_ptr || !mapping || !params || !bead_ptr || !entries || !energy || !forces || !status)
     return FMD_EINVAL;
-  const int need = kind == 2 ? 1 : (kind == 3 ? 3 : 2);
-  if (n_params < need || (kind == 3 && (n_params - 1) % 2 != 0)) return FMD_EINVAL;
+  const int need = kind == 2 ? 1 : (kind == 3 ? 3 : (kind == 6 ? 6 : 2));  // rows of params a kind reads at least
+  if (n_params < need || (kind == 3 && (n_params - 1) % 2 != 0) || (kind == 6 && n_params != 6)) return FMD_EINVAL;
   const size_t lds = (size_t)3 * max_beads_per_mol * sizeof(float);
   if (lds > 160 * 1024 - 256) return FMD_EUNSUPPORTED;
   hipStream_t s = fmd_stream(stream);
@@ -282,7 +312,10 @@ extern "C" int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr,
   if (kind == 0) FMD_PRIOR(0, false)
   else if (kind == 1) FMD_PRIOR(1, false)
   else if (kind == 2) FMD_PRIOR(2, true)
-  else FMD_PRIOR(3, false)
+  else if (kind == 3) FMD_PRIOR(3, false)
+  else if (kind == 4) FMD_PRIOR(4, false)
+  else if (kind == 5) FMD_PRIOR(5, false)
+  else FMD_PRIOR(6, false)
 #undef FMD_PRIOR
   FMD_CHECK_LAUNCH();
   return FMD_OK;

@@ -1,8 +1,9 @@
 """Classical prior terms (row N2): host mirror of the reference's prior classes and their condensed form.
 
-``HarmonicBonds`` / ``HarmonicAngles`` / ``Repulsion`` / ``Dihedral`` keep the reference's static
-``compute`` / ``compute_features`` (reference prior/harmonic.py:116-123,221-225,258-262,
-prior/repulsion.py:112-122, prior/fourier_series.py:154-192; features
+``HarmonicBonds`` / ``HarmonicAngles`` / ``HarmonicImpropers`` / ``Repulsion`` / ``Dihedral`` / ``QuarticAngles`` /
+``RestrictedQuartic`` keep the reference's static ``compute`` / ``compute_features`` (reference
+prior/harmonic.py:116-123,221-225,258-262,301-322, prior/repulsion.py:112-122, prior/fourier_series.py:154-192,
+prior/polynomial.py:127-186, prior/restricted_bending.py:200-238; features
 geometry/internal_coordinates.py:72-223) as plain torch ops -- the --disable_optim / CPU path.
 ``StaticPriors`` is the condensed form the simulation uses (reference simulation/specialize_prior.py:76-207):
 per-term parameter arrays, evaluated with energy and forces in one HIP kernel per kind
@@ -18,8 +19,10 @@ import torch
 from . import _ffi
 from ._ffi import call, ptr, stream
 
-KIND = {"bonds": 0, "angles": 1, "repulsion": 2, "dihedrals": 3}
-ORDER = {"bonds": 2, "angles": 3, "repulsion": 2, "dihedrals": 4}
+KIND = {"bonds": 0, "angles": 1, "repulsion": 2, "dihedrals": 3, "impropers": 4, "quartic_angles": 5,
+        "restricted_angles": 6}
+ORDER = {"bonds": 2, "angles": 3, "repulsion": 2, "dihedrals": 4, "impropers": 4, "quartic_angles": 3,
+         "restricted_angles": 3}
 
 
 def compute_distances(pos, mapping):
@@ -29,6 +32,11 @@ def compute_distances(pos, mapping):
 def compute_angles_cos(pos, mapping):
     dr1, dr2 = pos[mapping[0]] - pos[mapping[1]], pos[mapping[2]] - pos[mapping[1]]
     return (dr1 * dr2).sum(dim=1) / (dr1.norm(p=2, dim=1) * dr2.norm(p=2, dim=1))
+
+
+def compute_angles_raw(pos, mapping):
+    dr1, dr2 = pos[mapping[0]] - pos[mapping[1]], pos[mapping[2]] - pos[mapping[1]]
+    return torch.atan2(torch.cross(dr1, dr2, dim=1).norm(p=2, dim=1), (dr1 * dr2).sum(dim=1))
 
 
 def compute_torsions(pos, mapping):
@@ -55,6 +63,36 @@ class HarmonicAngles(HarmonicBonds):
     compute_features = staticmethod(compute_angles_cos)
 
 
+class HarmonicImpropers(HarmonicBonds):
+    name, _order = "impropers", 4
+    compute_features = staticmethod(compute_torsions)
+
+
+class QuarticAngles:
+    """Polynomial of the angle's cosine (reference prior/polynomial.py:127-186): V = V0 + sum_n k_n x^n."""
+    name, _order = "angles", 3
+    compute_features = staticmethod(compute_angles_cos)
+
+    @staticmethod
+    def compute(x, ks, V0):
+        V, x_pow = ks[0] * x, x
+        for k in ks[1:]:
+            x_pow = x_pow * x
+            V = V + k * x_pow
+        return V + V0
+
+
+class RestrictedQuartic:
+    """reference prior/restricted_bending.py:200-238, on the raw angle."""
+    name, _order = "angles", 3
+    compute_features = staticmethod(compute_angles_raw)
+
+    @staticmethod
+    def compute(x, a, b, c, d, k, v_0):
+        cos, sin = torch.cos(x), torch.sin(x)
+        return a * cos ** 4 + b * cos ** 3 + c * cos ** 2 + d * cos + k / (sin ** 2) + v_0
+
+
 class Repulsion:
     name, _order = "repulsion", 2
     compute_features = staticmethod(compute_distances)
@@ -79,10 +117,15 @@ class Dihedral:
 def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
     """per-term parameters [P, M] from per-type tables (what data2parameters does in the reference)."""
     idx = tuple(types[mapping[i]] for i in range(mapping.shape[0]))
-    if kind in ("bonds", "angles"):
+    if kind in ("bonds", "angles", "impropers"):
         return torch.stack([tables["k"][idx], tables["x_0"][idx]])
     if kind == "repulsion":
         return tables["sigma"][idx].unsqueeze(0)
+    if kind == "quartic_angles":     # rows v_0, k_1 .. k_n  (Polynomial.ks is [n_degs, *types])
+        return torch.cat([tables["v_0"][idx].unsqueeze(0)] + [tables["ks"][i][idx].unsqueeze(0)
+                                                              for i in range(tables["ks"].shape[0])])
+    if kind == "restricted_angles":
+        return torch.stack([tables[n][idx] for n in ("a", "b", "c", "d", "k", "v_0")])
     n = tables["k1s"].shape[0]
     return torch.cat([tables["v_0"][idx].unsqueeze(0)] + [tables["k1s"][i][idx].unsqueeze(0) for i in range(n)]
                      + [tables["k2s"][i][idx].unsqueeze(0) for i in range(n)])
@@ -92,14 +135,16 @@ def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Ten
     """The prior models of a reference-format container, read from its ``state_dict``: name -> (kind, per-type tables).
     The reference's prior classes keep their parameters as BUFFERS indexed by bead types: ``Harmonic.x_0`` / ``.k``
     (prior/harmonic.py:60-77; order 2 = bonds, order 3 = angles), ``Repulsion.sigma`` (prior/repulsion.py:52-60),
-    ``FourierSeries.k1s`` / ``.k2s`` / ``.v_0`` (prior/fourier_series.py:60-80; order 4 = dihedrals), each under
+    ``FourierSeries.k1s`` / ``.k2s`` / ``.v_0`` (prior/fourier_series.py:60-80; order 4 = dihedrals), ``Harmonic``
+    of order 4 = impropers, ``Polynomial.ks`` / ``.v_0`` (prior/polynomial.py:62-75; order 3 = quartic angles),
+    ``RestrictedQuartic.a`` .. ``.d`` / ``.k`` / ``.v_0`` (prior/restricted_bending.py:68-88), each under
     ``<prefix>.<name>.model.`` in ``SumOut.models`` (models/gradients.py:64-69).  The kind is told by the buffer set and
     its rank, the name is the ModuleDict key -- the key of ``data.neighbor_list`` the term's index mapping lives
     under.  The topology itself is not in the file: ``StaticPriors.from_state_dict`` takes it from the caller."""
     groups: Dict[str, Dict[str, torch.Tensor]] = {}
     for key, v in sd.items():
         head, _, leaf = key.rpartition(".")
-        if leaf in ("x_0", "k", "sigma", "k1s", "k2s", "v_0"):
+        if leaf in ("x_0", "k", "sigma", "k1s", "k2s", "v_0", "ks", "a", "b", "c", "d"):
             groups.setdefault(head, {})[leaf] = v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
     out = {}
     for head, bufs in groups.items():
@@ -110,6 +155,12 @@ def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Ten
             kind = "bonds"
         elif names == {"x_0", "k"} and bufs["k"].dim() == 3:
             kind = "angles"
+        elif names == {"x_0", "k"} and bufs["k"].dim() == 4:
+            kind = "impropers"
+        elif names == {"ks", "v_0"} and bufs["v_0"].dim() == 3:
+            kind = "quartic_angles"
+        elif names == {"a", "b", "c", "d", "k", "v_0"} and bufs["v_0"].dim() == 3:
+            kind = "restricted_angles"
         elif names == {"sigma"} and bufs["sigma"].dim() == 2:
             kind = "repulsion"
         elif names == {"k1s", "k2s", "v_0"} and bufs["v_0"].dim() == 4:
@@ -157,6 +208,9 @@ class StaticPriors:
                     z = torch.zeros(n_max - n, q.shape[1])
                     padded.append(torch.cat([q[:1 + n], z, q[1 + n:], z]))
                 looked = padded
+            if kind == "quartic_angles" and len(looked) > 1:   # rows: v_0, k_1..k_n -> zero coefficients up to the largest n
+                rows = max(q.shape[0] for q in looked)
+                looked = [torch.cat([q, torch.zeros(rows - q.shape[0], q.shape[1])]) for q in looked]
             params = torch.cat(looked, dim=1)
             mapping = torch.cat([mp for _, mp in members], dim=1)
             order, n_terms = mapping.shape
@@ -251,6 +305,12 @@ class StaticPriors:
                 e = HarmonicAngles.compute(compute_angles_cos(pos, mapping), p[1], p[0])
             elif kind == "repulsion":
                 e = Repulsion.compute(compute_distances(pos, mapping), p[0])
+            elif kind == "impropers":
+                e = HarmonicImpropers.compute(compute_torsions(pos, mapping), p[1], p[0])
+            elif kind == "quartic_angles":
+                e = QuarticAngles.compute(compute_angles_cos(pos, mapping), p[1:], p[0])
+            elif kind == "restricted_angles":
+                e = RestrictedQuartic.compute(compute_angles_raw(pos, mapping), *p)
             else:
                 n = (p.shape[0] - 1) // 2
                 e = Dihedral.compute(compute_torsions(pos, mapping), p[0], p[1:1 + n].t(), p[1 + n:].t())

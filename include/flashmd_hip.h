@@ -307,7 +307,14 @@ int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* m
  *   kind 2 repulsion  (prior/repulsion.py:80-122)          U = (sigma / d)^6           params rows: sigma
  *   kind 3 dihedrals  (prior/fourier_series.py:97-192)     U = v0 + sum_n k1_n sin(n phi) + k2_n cos(n phi)
  *                                                          params rows: v0, k1_1..k1_n, k2_1..k2_n
- *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4); params [n_params][n_terms] f32;
+ *   kind 4 impropers  (prior/harmonic.py:301-322: Harmonic.compute on compute_torsions)
+ *                                                          U = k (phi - x0)^2          params rows: k, x0
+ *   kind 5 quartic angles (prior/polynomial.py:127-186)    U = v0 + sum_n k_n cos(theta)^n
+ *                                                          params rows: v0, k_1..k_n (any n >= 1)
+ *   kind 6 restricted angles (prior/restricted_bending.py:200-238; theta = atan2(|r1 x r2|, r1 . r2))
+ *                                                          U = a c^4 + b c^3 + c c^2 + d c + k / sin(theta)^2 + v0
+ *                                                          params rows: a, b, c, d, k, v0
+ *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4/4/3/3); params [n_params][n_terms] f32;
  *   bead_ptr [N+1] i64 and entries [order * n_terms] i32 = the CSR of the fixed topology by bead: entry =
  *   term << 2 | slot, the entries of bead b are bead_ptr[b]..bead_ptr[b+1] in ascending (term, slot) order
  *   (built once per topology by the caller; n_terms < 2^29).  ADDS the per-molecule energies to energy[n_mol]

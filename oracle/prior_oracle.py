@@ -7,9 +7,14 @@ Follows, term by term:
   angles     prior/harmonic.py:228-262              U = k (cos(theta) - x0)^2
   repulsion  prior/repulsion.py:80-122              U = (sigma / d)^6
   dihedrals  prior/fourier_series.py:97-141,154-192 U = v0 + sum_n k1_n sin(n phi) + k2_n cos(n phi)
+  impropers  prior/harmonic.py:301-322              U = k (phi - x0)^2            (Harmonic.compute on the torsion)
+  quartic_angles     prior/polynomial.py:127-186    U = v0 + sum_n k_n cos(theta)^n
+  restricted_angles  prior/restricted_bending.py:200-238  U = a c^4 + b c^3 + c c^2 + d c + k / sin^2 + v0 on the raw
+                     angle theta = atan2(|r1 x r2|, r1 . r2) (geometry/internal_coordinates.py:104-135)
 Per-term parameters are looked up by bead type exactly as `data2parameters` does (table[types of the term]);
 energies are summed per molecule (`scatter(..., mapping_batch)`), forces are -dU/dpos by autograd.
-Pinned against the reference's own classes by oracle/make_golden_priors.py -> tests/golden/case_priors.npz.
+Pinned against the reference's own classes by oracle/make_golden_priors.py -> tests/golden/case_priors.npz and
+case_priors_more.npz (the last three kinds).
 """
 import torch
 
@@ -22,6 +27,12 @@ def angles_cos(pos, mapping):
     dr1 = pos[mapping[0]] - pos[mapping[1]]
     dr2 = pos[mapping[2]] - pos[mapping[1]]
     return (dr1 * dr2).sum(dim=1) / (dr1.norm(p=2, dim=1) * dr2.norm(p=2, dim=1))
+
+
+def angles_raw(pos, mapping):
+    dr1 = pos[mapping[0]] - pos[mapping[1]]
+    dr2 = pos[mapping[2]] - pos[mapping[1]]
+    return torch.atan2(torch.cross(dr1, dr2, dim=1).norm(p=2, dim=1), (dr1 * dr2).sum(dim=1))
 
 
 def torsions(pos, mapping):
@@ -50,16 +61,33 @@ def term_energies(kind, pos, mapping, params):
         deg = torch.arange(1, n + 1, dtype=pos.dtype).view(-1, 1)
         ang = phi.view(1, -1) * deg
         return params[0] + (params[1:1 + n] * torch.sin(ang) + params[1 + n:] * torch.cos(ang)).sum(0)
+    if kind == "impropers":
+        return params[0] * (torsions(pos, mapping) - params[1]) ** 2           # k, x0
+    if kind == "quartic_angles":                                               # v0, k_1 .. k_n
+        x = angles_cos(pos, mapping)
+        v, xp = params[1] * x, x
+        for q in range(2, params.shape[0]):
+            xp = xp * x
+            v = v + params[q] * xp
+        return v + params[0]
+    if kind == "restricted_angles":                                            # a, b, c, d, k, v0
+        th = angles_raw(pos, mapping)
+        c, s = torch.cos(th), torch.sin(th)
+        return params[0] * c ** 4 + params[1] * c ** 3 + params[2] * c ** 2 + params[3] * c + params[4] / s ** 2 + params[5]
     raise ValueError(kind)
 
 
 def lookup(kind, tables, types, mapping):
     """per-term parameters from per-type tables, as data2parameters does."""
     idx = tuple(types[mapping[i]] for i in range(mapping.shape[0]))
-    if kind in ("bonds", "angles"):
+    if kind in ("bonds", "angles", "impropers"):
         return torch.stack([tables["k"][idx], tables["x_0"][idx]])
     if kind == "repulsion":
         return tables["sigma"][idx].unsqueeze(0)
+    if kind == "quartic_angles":
+        return torch.cat([tables["v_0"][idx].unsqueeze(0), torch.stack([tables["ks"][i][idx] for i in range(tables["ks"].shape[0])])])
+    if kind == "restricted_angles":
+        return torch.stack([tables[n][idx] for n in ("a", "b", "c", "d", "k", "v_0")])
     n = tables["k1s"].shape[0]
     return torch.cat([tables["v_0"][idx].unsqueeze(0), torch.stack([tables["k1s"][i][idx] for i in range(n)]),
                       torch.stack([tables["k2s"][i][idx] for i in range(n)])])

@@ -10,13 +10,14 @@ import torch
 from oracle import prior_oracle as po
 
 KINDS = ("bonds", "angles", "repulsion", "dihedrals")
+MORE = ("impropers", "quartic_angles", "restricted_angles")   # case_priors_more.npz (make_golden_priors.py more)
 
 
-def _load(golden_dir):
-    z = np.load(os.path.join(golden_dir, "case_priors.npz"))
+def _load(golden_dir, name="case_priors.npz", kinds=KINDS):
+    z = np.load(os.path.join(golden_dir, name))
     pos, types, ptr = (torch.from_numpy(z[k]) for k in ("pos", "types", "ptr"))
-    tables = {k: {n[len(k) + 7:]: torch.from_numpy(z[n]) for n in z.files if n.startswith(k + "_table_")} for k in KINDS}
-    maps = {k: torch.from_numpy(z[k + "_mapping"]) for k in KINDS}
+    tables = {k: {n[len(k) + 7:]: torch.from_numpy(z[n]) for n in z.files if n.startswith(k + "_table_")} for k in kinds}
+    maps = {k: torch.from_numpy(z[k + "_mapping"]) for k in kinds}
     return z, pos, types, ptr, tables, maps
 
 
@@ -37,6 +38,43 @@ def test_prior_oracle_matches_reference_vectors(golden_dir):
         terms.append((k, maps[k], prm))
     e, f = po.prior_energy_forces(pos.double(), terms, mol_of_bead, n_mol)
     assert _rel(e, z["total_energy_ref64"]) < 1e-12 and _rel(f, z["total_forces_ref64"]) < 1e-12
+
+
+def test_more_prior_kinds_oracle_and_host_mirror_match_reference_vectors(golden_dir):
+    """HarmonicImpropers, QuarticAngles, RestrictedQuartic: oracle and the host mirror's torch path against the
+    reference classes' fp64 outputs; a state_dict with these buffers is recognised by kind."""
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir, "case_priors_more.npz", MORE)
+    n_mol = ptr.numel() - 1
+    mol_of_bead = torch.repeat_interleave(torch.arange(n_mol), ptr[1:] - ptr[:-1])
+    terms = []
+    for k in MORE:
+        prm = po.lookup(k, tables[k], types, maps[k])
+        e, f = po.prior_energy_forces(pos.double(), [(k, maps[k], prm)], mol_of_bead, n_mol)
+        assert _rel(e, z[k + "_energy_ref64"]) < 1e-12 and _rel(f, z[k + "_forces_ref64"]) < 1e-11, k
+        terms.append((k, maps[k], prm))
+    e, f = po.prior_energy_forces(pos.double(), terms, mol_of_bead, n_mol)
+    assert _rel(e, z["total_energy_ref64"]) < 1e-12 and _rel(f, z["total_forces_ref64"]) < 1e-11
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in MORE}, types, ptr)
+    x = pos.double().requires_grad_(True)
+    e = sp.energy_torch(x, ptr)
+    (g,) = torch.autograd.grad(e.sum(), x)
+    assert _rel(e.detach(), z["total_energy_ref64"]) < 1e-6 and _rel(-g, z["total_forces_ref64"]) < 1e-6
+    sd = {f"models.{k}.model.{n}": t for k in MORE for n, t in tables[k].items()}
+    found = prior.prior_tables_from_state_dict(sd)
+    assert {k: v[0] for k, v in found.items()} == {k: k for k in MORE}
+    sp2 = prior.StaticPriors.from_state_dict(sd, maps, types, ptr)
+    assert _rel(sp2.energy_torch(pos.double(), ptr), z["total_energy_ref64"]) < 1e-6
+    # two polynomial models of different degree condense into one list (zero coefficients up to the longer one)
+    short = {"v_0": tables["quartic_angles"]["v_0"], "ks": tables["quartic_angles"]["ks"][:2]}
+    ma = maps["quartic_angles"]
+    hf = ma.shape[1] // 2
+    both = prior.StaticPriors.from_tables({"quartic_angles": [(tables["quartic_angles"], ma[:, :hf]), (short, ma[:, hf:])]},
+                                          types, ptr)
+    parts = [prior.StaticPriors.from_tables({"quartic_angles": (tables["quartic_angles"], ma[:, :hf])}, types, ptr),
+             prior.StaticPriors.from_tables({"quartic_angles": (short, ma[:, hf:])}, types, ptr)]
+    assert _rel(both.energy_torch(pos.double(), ptr), sum(q.energy_torch(pos.double(), ptr) for q in parts)) < 1e-12
 
 
 def test_prior_host_mirror_torch_path_matches_reference_vectors(golden_dir):
@@ -70,6 +108,39 @@ def test_prior_hip_vs_reference_vectors(golden_dir):
         one = prior.StaticPriors.from_tables({k: (tables[k], maps[k])}, types, ptr).to(dev)
         ek, fk = one.energy_forces(pos.to(dev), ptr.to(dev))
         assert _rel(ek.cpu(), z[k + "_energy_ref64"]) < 1e-5 and _rel(fk.cpu(), z[k + "_forces_ref64"]) < 2e-5, k
+
+
+@pytest.mark.gpu
+def test_more_prior_kinds_hip_vs_reference_vectors(golden_dir):
+    """kinds 4-6 of fmd_prior_energy_forces against the reference classes' fp64 outputs, each alone and summed, and on
+    269-bead chains against the fp64 oracle"""
+    from flashmd_amd import prior, synthetic
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir, "case_priors_more.npz", MORE)
+    dev = "cuda:0"
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in MORE}, types, ptr).to(dev)
+    e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    re, rf = _rel(e.cpu(), z["total_energy_ref64"]), _rel(f.cpu(), z["total_forces_ref64"])
+    print(f"impropers + quartic + restricted angles (HIP, fp32) vs reference fp64: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-5 and rf < 2e-5
+    e2, f2 = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    for k in MORE:
+        one = prior.StaticPriors.from_tables({k: (tables[k], maps[k])}, types, ptr).to(dev)
+        ek, fk = one.energy_forces(pos.to(dev), ptr.to(dev))
+        rek, rfk = _rel(ek.cpu(), z[k + "_energy_ref64"]), _rel(fk.cpu(), z[k + "_forces_ref64"])
+        print(f"  {k}: energy {rek:.2e} forces {rfk:.2e}")
+        assert rek < 1e-5 and rfk < 3e-5, k
+    n_mol, A, T = 8, 269, 5
+    pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
+    topo = synthetic.chain_topology(n_mol, A)
+    big = {"impropers": topo["dihedrals"], "quartic_angles": topo["angles"], "restricted_angles": topo["angles"]}
+    mol_of_bead = torch.arange(n_mol).repeat_interleave(A)
+    terms = [(k, big[k], po.lookup(k, tables[k], types, big[k]).double()) for k in MORE]
+    e_o, f_o = po.prior_energy_forces(pos.double(), terms, mol_of_bead, n_mol)
+    sp = prior.StaticPriors.from_tables({k: (tables[k], big[k]) for k in MORE}, types, ptr).to(dev)
+    e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    assert _rel(e.cpu(), e_o) < 1e-5 and _rel(f.cpu(), f_o) < 3e-5
 
 
 @pytest.mark.gpu
