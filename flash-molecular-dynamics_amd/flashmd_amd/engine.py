@@ -4,7 +4,7 @@
 Replaces, for qualifying models, what the reference does per timestep in SchNet.forward +
 GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model
 qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
-<= 64 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
+<= 128 functions (above 64: molecules up to 283 beads), cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
 tanh, hidden <= 128 and filters <= 128 (the kernels are built for 128 x 128: narrower layers are zero-padded when the
 weights are packed, which is exact -- a padded feature is 0 in every layer -- and costs the padded arithmetic), a 2- or
 3-linear output MLP with widths <= 128, fp32 weights (or the W16A16 twins of models/gptq.py on both the filter and
@@ -208,7 +208,10 @@ class FusedSchNetEngine:
             self._ws = None
             wants_stash = self.desc.precision == PRECISIONS["f32"] and not (self._flags & _ffi.FLAG_NO_FILTER_STASH)
             stash = (self.desc.num_blocks - 1) * n_mol * cap * 512
-            if wants_stash and stash > min(MAX_STASH_BYTES, torch.cuda.mem_get_info(self.device)[0] // 2):
+            # (free = what the driver reports plus what torch's caching allocator holds unused: the old workspace is there)
+            free = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) \
+                - torch.cuda.memory_allocated(self.device)
+            if wants_stash and stash > min(MAX_STASH_BYTES, free // 2):
                 self.desc.flags = self._flags | _ffi.FLAG_NO_FILTER_STASH
 
             def alloc():
