@@ -2,7 +2,11 @@
 // respect to x1 (-> gx1 aggregate) and to the pair distance (-> dE/dd, including the d/dd of the cutoff that the
 // reference's Triton path drops).  Replaces K6/K7 + K10/K2 (kernels/cfconv_kernels.py:973-1035,
 // 1174-1208,178-258; csr_kernels.py:302-396) and the autograd chain through them on the whole-path route.
+// Compiled twice, as the forward kernel's file: as itself the fp32-grade kernels with scalar pair arithmetic;
+// included by fmd_engine_edge_bwd_half.hip with FMD_HALF_TU set, the W16A16 kernels with the packed pair type.
+#ifndef FMD_HALF_TU
 #define FMD_SCALAR_PAIRS 1
+#endif
 #include "fmd_engine.h"
 
 namespace {
@@ -723,22 +727,35 @@ namespace fmd_eng {
   M_(true, true, false, true, false, false) M_(true, false, false, true, false, false)         \
   M_(true, true, true, true, false, false) M_(true, false, true, true, false, false)           \
   M_(true, true, true, true, true, false) M_(true, false, true, true, true, false)
-#define FMD_BWD_ALL(M_)                                                                         \
-  FMD_BWD_F32(M_, false) FMD_BWD_F32(M_, true) FMD_BWD_HALF(M_)                                 \
+// block 0 (no gx1 aggregate)
+#define FMD_BWD_B0_F32(M_)                                                                      \
   M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
-  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
   M_(false, true, true, false, false, false) M_(false, false, true, false, false, false)       \
+  M_(false, true, true, false, true, false) M_(false, false, true, false, true, false)
+#define FMD_BWD_B0_HALF(M_)                                                                     \
+  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
   M_(false, true, true, true, false, false) M_(false, false, true, true, false, false)         \
-  M_(false, true, true, false, true, false) M_(false, false, true, false, true, false)         \
   M_(false, true, true, true, true, false) M_(false, false, true, true, true, false)
-
 // NS0 = 8 (65..128 Gaussians): the per-wave Gaussian form in whole-aggregate mode only
-#define FMD_BWD_WIDE(M_)                                                                        \
+#define FMD_BWD_WIDE_F32(M_)                                                                    \
   M_(true, true, false, false, false, false) M_(true, false, false, false, false, false)       \
   M_(true, true, false, false, false, true) M_(true, false, false, false, false, true)         \
+  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)
+#define FMD_BWD_WIDE_HALF(M_)                                                                   \
   M_(true, true, false, true, false, false) M_(true, false, false, true, false, false)         \
-  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
   M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)
+#ifdef FMD_HALF_TU   // this translation unit: the W16A16 kernels, reached through the *_half entry points
+#define FMD_TU(x) x##_half
+#define FMD_BWD_MINE(M_) if constexpr (NS0 > 4) { FMD_BWD_WIDE_HALF(M_) } else { FMD_BWD_HALF(M_) FMD_BWD_B0_HALF(M_) }
+#else
+#define FMD_TU(x) x
+#define FMD_BWD_MINE(M_)                                 \
+  if constexpr (NS0 > 4) { FMD_BWD_WIDE_F32(M_) }        \
+  else { FMD_BWD_F32(M_, false) FMD_BWD_F32(M_, true) FMD_BWD_B0_F32(M_) }
+#endif
+int setup_edge_bwd_attrs_half();
+int launch_edge_bwd_half(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol,
+                         hipStream_t s);
 
 template <int NS0>
 static int set_attrs() {
@@ -746,14 +763,17 @@ static int set_attrs() {
   if (hipFuncSetAttribute((const void*)edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_>,                  \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)      \
     return FMD_ELAUNCH;
-  if constexpr (NS0 > 4) { FMD_BWD_WIDE(FMD_ONE) } else { FMD_BWD_ALL(FMD_ONE) }
+  FMD_BWD_MINE(FMD_ONE)
 #undef FMD_ONE
   return FMD_OK;
 }
-int setup_edge_bwd_attrs() {
+int FMD_TU(setup_edge_bwd_attrs)() {
   int rc = set_attrs<2>();
   if (rc == FMD_OK) rc = set_attrs<4>();
   if (rc == FMD_OK) rc = set_attrs<8>();
+#ifndef FMD_HALF_TU
+  if (rc == FMD_OK) rc = setup_edge_bwd_attrs_half();
+#endif
   return rc;
 }
 
@@ -775,13 +795,16 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
     edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a);      \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                         \
   }
-  if constexpr (NS0 > 4) { FMD_BWD_WIDE(FMD_ONE) } else { FMD_BWD_ALL(FMD_ONE) }
+  FMD_BWD_MINE(FMD_ONE)
 #undef FMD_ONE
   return FMD_EUNSUPPORTED;
 }
 
-int launch_edge_bwd(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol,
-                    hipStream_t s) {
+int FMD_TU(launch_edge_bwd)(const EdgeArgs& a, int num_rbf, bool half, bool need_gx1, bool first, int64_t n_mol,
+                            hipStream_t s) {
+#ifndef FMD_HALF_TU
+  if (half) return launch_edge_bwd_half(a, num_rbf, half, need_gx1, first, n_mol, s);
+#endif
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
   return num_rbf <= 32   ? launch_bwd<2>(a, half, need_gx1, first, grid, s)
          : num_rbf <= 64 ? launch_bwd<4>(a, half, need_gx1, first, grid, s)

@@ -2,7 +2,13 @@
 // CFConv message passing (schnet.py:706-715) of one interaction block over the undirected pair list; the molecule's
 // aggregate stays in LDS.  Replaces K3/K4/K5 + K9 of the reference (kernels/cfconv_kernels.py:469-540,657-720,
 // 780-832; csr_kernels.py:625-724) on the whole-path route.
+// This file is compiled twice: as itself it holds the fp32-grade kernels, whose pair arithmetic is SCALAR
+// (FMD_SCALAR_PAIRS, fmd_engine.h: packed fp32 cannot issue beside the partner wave's MFMAs, and these kernels are three
+// MFMAs per product); fmd_engine_edge_fwd_half.hip includes it with FMD_HALF_TU set and holds the W16A16 kernels, one
+// MFMA per product, which are faster with the PACKED pair type (same-box A/B, profiles/r05_ab_packed_half.txt).
+#ifndef FMD_HALF_TU
 #define FMD_SCALAR_PAIRS 1
+#endif
 #include "fmd_engine.h"
 
 namespace {
@@ -548,6 +554,28 @@ namespace fmd_eng {
 // (HALF, FS, SH); the stash variants exist in fp32-grade precision only (no stash is ever allocated for W16A16)
 #define FMD_FWD_F32(M_) M_(false, false, false) M_(false, true, false) M_(false, false, true)
 #define FMD_FWD_HALF(M_) M_(true, false, false) M_(true, true, false) M_(true, false, true)
+#ifdef FMD_HALF_TU   // this translation unit: the W16A16 kernels, reached through the *_half entry points
+constexpr bool TU_HALF = true;
+#define FMD_TU(x) x##_half
+#else
+constexpr bool TU_HALF = false;
+#define FMD_TU(x) x
+#endif
+int setup_edge_fwd_attrs_half();
+int launch_edge_fwd_half(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s);
+
+// the instantiations of this translation unit for (NS0, STASH), handed to M_
+#define FMD_FWD_MINE(M_)                                          \
+  if constexpr (TU_HALF) {                                        \
+    if constexpr (!STASH) {                                       \
+      if constexpr (NS0 > 4) { M_(true, false, false) }           \
+      else { FMD_FWD_HALF(M_) }                                   \
+    }                                                             \
+  } else if constexpr (NS0 > 4) {                                 \
+    M_(false, false, false) /* 65..128 Gaussians: per-wave Gaussian form, whole-aggregate mode */ \
+  } else {                                                        \
+    FMD_FWD_F32(M_)                                               \
+  }
 
 template <int NS0, bool STASH>
 static int set_fwd_attrs() {
@@ -555,23 +583,20 @@ static int set_fwd_attrs() {
   if (hipFuncSetAttribute((const void*)edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH>,                        \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MAX_LDS_BYTES) != hipSuccess)       \
     return FMD_ELAUNCH;
-  if constexpr (NS0 > 4) {   // 65..128 Gaussians: per-wave Gaussian form, whole-aggregate mode
-    FMD_ONE(false, false, false)
-    if constexpr (!STASH) { FMD_ONE(true, false, false) }
-  } else {
-    FMD_FWD_F32(FMD_ONE)
-    if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
-  }
+  FMD_FWD_MINE(FMD_ONE)
 #undef FMD_ONE
   return FMD_OK;
 }
-int setup_edge_fwd_attrs() {
+int FMD_TU(setup_edge_fwd_attrs)() {
   int rc = set_fwd_attrs<2, false>();
   if (rc == FMD_OK) rc = set_fwd_attrs<2, true>();
   if (rc == FMD_OK) rc = set_fwd_attrs<4, false>();
   if (rc == FMD_OK) rc = set_fwd_attrs<4, true>();
   if (rc == FMD_OK) rc = set_fwd_attrs<8, false>();
   if (rc == FMD_OK) rc = set_fwd_attrs<8, true>();
+#ifndef FMD_HALF_TU
+  if (rc == FMD_OK) rc = setup_edge_fwd_attrs_half();
+#endif
   return rc;
 }
 
@@ -589,18 +614,15 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
     edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH><<<grid, 512, (SH_) ? lds_sh : lds, s>>>(a);  \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                \
   }
-  if constexpr (NS0 > 4) {
-    FMD_ONE(false, false, false)
-    if constexpr (!STASH) { FMD_ONE(true, false, false) }
-  } else {
-    FMD_FWD_F32(FMD_ONE)
-    if constexpr (!STASH) { FMD_FWD_HALF(FMD_ONE) }
-  }
+  FMD_FWD_MINE(FMD_ONE)
 #undef FMD_ONE
   return FMD_EUNSUPPORTED;
 }
 
-int launch_edge_fwd(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
+int FMD_TU(launch_edge_fwd)(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mol, hipStream_t s) {
+#ifndef FMD_HALF_TU
+  if (half) return launch_edge_fwd_half(a, num_rbf, half, n_mol, s);
+#endif
   const dim3 grid((unsigned)a.n_split, (unsigned)n_mol);
   if (a.wst && !half)
     return num_rbf <= 32 ? launch_fwd<2, true>(a, half, grid, s)
