@@ -630,11 +630,23 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
           constexpr int q = decltype(qc)::value;
           if (NEED_GX1) {
             float si = 0.f;
+            if constexpr (HALF) {  // packed pairs, as in the forward kernel
+              const f32x2 w01 = f32x2{fl[4 * q], fl[4 * q + 1]}, w23 = f32x2{fl[4 * q + 2], fl[4 * q + 3]};
+              const f32x2 n01 = f32x2{vj[0], vj[1]} + splat2(X.gi[q]) * w01;
+              const f32x2 n23 = f32x2{vj[2], vj[3]} + splat2(X.gi[q]) * w23;
+              const f32x2 s2 = f32x2{X.gj[4 * q], X.gj[4 * q + 1]} * w01 + f32x2{X.gj[4 * q + 2], X.gj[4 * q + 3]} * w23;
+              agg_wr(X.oj[4 * q], n01[0]);
+              agg_wr(X.oj[4 * q + 1], n01[1]);
+              agg_wr(X.oj[4 * q + 2], n23[0]);
+              agg_wr(X.oj[4 * q + 3], n23[1]);
+              si = s2[0] + s2[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float Wqe = fl[4 * q + e];  // already filt * C
-              si += X.gj[4 * q + e] * Wqe;
-              agg_wr(X.oj[4 * q + e], vj[e] + X.gi[q] * Wqe);
+              for (int e = 0; e < 4; ++e) {
+                const float Wqe = fl[4 * q + e];  // already filt * C
+                si += X.gj[4 * q + e] * Wqe;
+                agg_wr(X.oj[4 * q + e], vj[e] + X.gi[q] * Wqe);
+              }
             }
             si = fmd_segment_sum(si, X.oi[q]);
             agg_wr(X.oi[q], cval + si);

@@ -369,12 +369,24 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           for (int e = 0; e < 4; ++e) {
             Wq[e] = fl[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
             vj[e] = agg_rd(X.oj[4 * q + e]);
-            si += X.xj[4 * q + e] * Wq[e];
+            if (!HALF) si += X.xj[4 * q + e] * Wq[e];
           }
           const float cval = agg_rd(X.oi[q]);
+          if constexpr (HALF) {  // the arithmetic of the tile loop's update (same bits wherever a tile is processed)
+            const f32x2 w01 = f32x2{Wq[0], Wq[1]}, w23 = f32x2{Wq[2], Wq[3]};
+            const f32x2 n01 = f32x2{vj[0], vj[1]} + splat2(X.xi[q]) * w01;
+            const f32x2 n23 = f32x2{vj[2], vj[3]} + splat2(X.xi[q]) * w23;
+            const f32x2 s2 = f32x2{X.xj[4 * q], X.xj[4 * q + 1]} * w01 + f32x2{X.xj[4 * q + 2], X.xj[4 * q + 3]} * w23;
+            agg_wr(X.oj[4 * q], n01[0]);
+            agg_wr(X.oj[4 * q + 1], n01[1]);
+            agg_wr(X.oj[4 * q + 2], n23[0]);
+            agg_wr(X.oj[4 * q + 3], n23[1]);
+            si = s2[0] + s2[1];
+          } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wq[e]);
+            for (int e = 0; e < 4; ++e)
+              agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wq[e]);
+          }
           si = fmd_segment_sum(si, X.oi[q]);
           // both halves store the same value to the same address
           agg_wr(X.oi[q], cval + si);
@@ -415,11 +427,23 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           auto seg_finish = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             float si = 0.f;
+            if constexpr (HALF) {  // packed pairs (this translation unit's f32x2): two fmas per product pair, (0 + 2) + (1 + 3)
+              const f32x2 w01 = f32x2{fl_prev[4 * q], fl_prev[4 * q + 1]}, w23 = f32x2{fl_prev[4 * q + 2], fl_prev[4 * q + 3]};
+              const f32x2 n01 = f32x2{vj[0], vj[1]} + splat2(X.xi[q]) * w01;
+              const f32x2 n23 = f32x2{vj[2], vj[3]} + splat2(X.xi[q]) * w23;
+              const f32x2 s2 = f32x2{X.xj[4 * q], X.xj[4 * q + 1]} * w01 + f32x2{X.xj[4 * q + 2], X.xj[4 * q + 3]} * w23;
+              agg_wr(X.oj[4 * q], n01[0]);
+              agg_wr(X.oj[4 * q + 1], n01[1]);
+              agg_wr(X.oj[4 * q + 2], n23[0]);
+              agg_wr(X.oj[4 * q + 3], n23[1]);
+              si = s2[0] + s2[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float Wqe = fl_prev[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
-              si += X.xj[4 * q + e] * Wqe;
-              agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wqe);
+              for (int e = 0; e < 4; ++e) {
+                const float Wqe = fl_prev[4 * q + e];  // already filt * C (the hidden tile carries the cutoff)
+                si += X.xj[4 * q + e] * Wqe;
+                agg_wr(X.oj[4 * q + e], vj[e] + X.xi[q] * Wqe);
+              }
             }
             si = fmd_segment_sum(si, X.oi[q]);
             // both halves store the same value to the same address
