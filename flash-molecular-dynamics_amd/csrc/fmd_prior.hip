@@ -7,6 +7,8 @@
 //   impropers  prior/harmonic.py:301-322 (Harmonic.compute :116-118 on compute_torsions)   U = k (phi - x0)^2
 //   quartic angles     prior/polynomial.py:127-186    U = v0 + sum_n k_n cos(theta)^n
 //   restricted angles  prior/restricted_bending.py:200-238   U = a c^4 + b c^3 + c c^2 + d c + k / sin(theta)^2 + v0, c = cos(theta)
+//   raw angles         prior/harmonic.py:264-298 (HarmonicAnglesRaw)            U = k (theta - x0)^2, theta = atan2(|r1 x r2|, r1 . r2)
+//   shifted impropers  prior/harmonic.py:325-400 (ShiftedPeriodicHarmonicImpropers)  U = k (phi' - x0)^2, phi' = (phi < 0 ? phi + 2 pi : phi) - pi
 // with the features of geometry/internal_coordinates.py:72-223.  Energy and the analytic -dU/dpos are added to
 // energy[B] / forces[N,3] in one pass, as a GATHER over the fixed topology: one workgroup per molecule keeps the
 // molecule's positions in LDS, one wave per bead walks that bead's (term, slot) entries (a CSR built once on the
@@ -30,7 +32,8 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 
 // WAVE_PER_BEAD: lanes of a wave share one bead's entries (long lists: the repulsion pairs); otherwise one lane
 // per bead walks its own few entries (bonded terms: <= 2..4 entries per bead) and the whole molecule is one pass.
-// 0 bonds, 1 angles (cos), 2 repulsion, 3 dihedrals, 4 impropers, 5 quartic angles, 6 restricted angles
+// 0 bonds, 1 angles (cos), 2 repulsion, 3 dihedrals, 4 impropers, 5 quartic angles, 6 restricted angles, 7 raw angles,
+// 8 shifted-periodic impropers
 template <int KIND, bool WAVE_PER_BEAD>
 __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ pos,
                                                      const int64_t* __restrict__ mol_ptr,
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
                                                      const int32_t* __restrict__ entries, int64_t n_terms,
                                                      float* __restrict__ energy, float* __restrict__ forces,
                                                      int32_t* __restrict__ status, int max_beads) {
-  constexpr int ORDER = KIND == 0 || KIND == 2 ? 2 : (KIND == 3 || KIND == 4 ? 4 : 3);
+  constexpr int ORDER = KIND == 0 || KIND == 2 ? 2 : (KIND == 3 || KIND == 4 || KIND == 8 ? 4 : 3);
   extern __shared__ __attribute__((aligned(16))) float sp[];  // [3n] positions of the molecule
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t a0 = mol_ptr[m];
@@ -106,6 +109,12 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
             u = (u + kq) * c;
           }
           u += params[t];
+        } else if (KIND == 7) {  // rows: k, x0 on the raw angle; d theta / d cos = -1 / sin
+          const float k = params[t], x0 = params[n_terms + t];
+          const V3 nx = cross(r1, r2);
+          const float sn = sqrtf(dot(nx, nx)), th = atan2f(sn, dot(r1, r2));
+          u = k * (th - x0) * (th - x0);
+          de = -2.0f * k * (th - x0) * (n1 * n2) / sn;
         } else {  // rows: a, b, c, d, k, v0; theta = atan2(|r1 x r2|, r1 . r2) => sin^2 = |r1 x r2|^2 / (n1 n2)^2
           const float pa = params[t], pb = params[n_terms + t], pc = params[2 * n_terms + t];
           const float pd = params[3 * n_terms + t], pk = params[4 * n_terms + t], v0 = params[5 * n_terms + t];
@@ -125,10 +134,11 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ p
         const V3 n1 = cross(u1, u2), n2 = cross(u2, u3), m1 = cross(n1, u2);
         const float phi = atan2f(-dot(m1, n2), dot(n1, n2));
         float du;  // dU/dphi
-        if (KIND == 4) {
+        if (KIND == 4 || KIND == 8) {
           const float k = params[t], x0 = params[n_terms + t];
-          u = k * (phi - x0) * (phi - x0);
-          du = 2.0f * k * (phi - x0);
+          const float ps = KIND == 8 ? (phi < 0.f ? phi + 6.283185307179586f : phi) - 3.141592653589793f : phi;
+          u = k * (ps - x0) * (ps - x0);
+          du = 2.0f * k * (ps - x0);
         } else {
           const int n_deg = (n_params - 1) / 2;
           du = 0.f;
@@ -289,7 +299,7 @@ extern "C" int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr,
                                        const float* params, int n_params, const int64_t* bead_ptr,
                                        const int32_t* entries, int64_t n_terms, float* energy, float* forces,
                                        int32_t* status, void* stream) {
-  if (n_mol < 0 || n_terms < 0 || max_beads_per_mol < 1 || kind < 0 || kind > 6) return FMD_EINVAL;
+  if (n_mol < 0 || n_terms < 0 || max_beads_per_mol < 1 || kind < 0 || kind > 8) return FMD_EINVAL;
   if (n_mol == 0 || n_terms == 0) return FMD_OK;
   if (n_terms >= ((int64_t)1 << 29)) return FMD_EUNSUPPORTED;  // entries pack (term << 2 | slot) in 32 bits
   if (!pos || !mol_ptr || !mapping || !params || !bead_ptr || !entries || !energy || !forces || !status)
@@ -315,7 +325,9 @@ extern "C" int fmd_prior_energy_forces(const float* pos, const int64_t* mol_ptr,
   else if (kind == 3) FMD_PRIOR(3, false)
   else if (kind == 4) FMD_PRIOR(4, false)
   else if (kind == 5) FMD_PRIOR(5, false)
-  else FMD_PRIOR(6, false)
+  else if (kind == 6) FMD_PRIOR(6, false)
+  else if (kind == 7) FMD_PRIOR(7, false)
+  else FMD_PRIOR(8, false)
 #undef FMD_PRIOR
   FMD_CHECK_LAUNCH();
   return FMD_OK;

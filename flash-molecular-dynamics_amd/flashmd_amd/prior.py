@@ -20,9 +20,9 @@ from . import _ffi
 from ._ffi import call, ptr, stream
 
 KIND = {"bonds": 0, "angles": 1, "repulsion": 2, "dihedrals": 3, "impropers": 4, "quartic_angles": 5,
-        "restricted_angles": 6}
+        "restricted_angles": 6, "raw_angles": 7, "shifted_impropers": 8}
 ORDER = {"bonds": 2, "angles": 3, "repulsion": 2, "dihedrals": 4, "impropers": 4, "quartic_angles": 3,
-         "restricted_angles": 3}
+         "restricted_angles": 3, "raw_angles": 3, "shifted_impropers": 4}
 
 
 def compute_distances(pos, mapping):
@@ -66,6 +66,23 @@ class HarmonicAngles(HarmonicBonds):
 class HarmonicImpropers(HarmonicBonds):
     name, _order = "impropers", 4
     compute_features = staticmethod(compute_torsions)
+
+
+class HarmonicAnglesRaw(HarmonicBonds):
+    """Harmonic in the raw angle (reference prior/harmonic.py:264-298; not exported by the package)."""
+    name, _order = "angles", 3
+    compute_features = staticmethod(compute_angles_raw)
+
+
+class ShiftedPeriodicHarmonicImpropers(HarmonicBonds):
+    """reference prior/harmonic.py:325-400: torsions below zero are shifted by 2 pi, then pi is subtracted."""
+    name, _order = "impropers", 4
+
+    @staticmethod
+    def compute_features(pos, mapping):
+        f = compute_torsions(pos, mapping)
+        pi32 = float(torch.tensor(torch.pi, dtype=torch.float32))   # the reference's torch_pi is a float32 tensor (:19)
+        return torch.where(f < 0, f + 2 * pi32, f) - pi32
 
 
 class QuarticAngles:
@@ -117,7 +134,7 @@ class Dihedral:
 def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
     """per-term parameters [P, M] from per-type tables (what data2parameters does in the reference)."""
     idx = tuple(types[mapping[i]] for i in range(mapping.shape[0]))
-    if kind in ("bonds", "angles", "impropers"):
+    if kind in ("bonds", "angles", "impropers", "raw_angles", "shifted_impropers"):
         return torch.stack([tables["k"][idx], tables["x_0"][idx]])
     if kind == "repulsion":
         return tables["sigma"][idx].unsqueeze(0)
@@ -307,6 +324,11 @@ class StaticPriors:
                 e = Repulsion.compute(compute_distances(pos, mapping), p[0])
             elif kind == "impropers":
                 e = HarmonicImpropers.compute(compute_torsions(pos, mapping), p[1], p[0])
+            elif kind == "raw_angles":
+                e = HarmonicAnglesRaw.compute(compute_angles_raw(pos, mapping), p[1], p[0])
+            elif kind == "shifted_impropers":
+                e = ShiftedPeriodicHarmonicImpropers.compute(ShiftedPeriodicHarmonicImpropers.compute_features(pos, mapping),
+                                                             p[1], p[0])
             elif kind == "quartic_angles":
                 e = QuarticAngles.compute(compute_angles_cos(pos, mapping), p[1:], p[0])
             elif kind == "restricted_angles":

@@ -314,7 +314,10 @@ int fmd_pt_swap_local(float* x, float* v, const int64_t* mol_a, const int64_t* m
  *   kind 6 restricted angles (prior/restricted_bending.py:200-238; theta = atan2(|r1 x r2|, r1 . r2))
  *                                                          U = a c^4 + b c^3 + c c^2 + d c + k / sin(theta)^2 + v0
  *                                                          params rows: a, b, c, d, k, v0
- *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4/4/3/3); params [n_params][n_terms] f32;
+ *   kind 7 raw angles (prior/harmonic.py:264-298)           U = k (theta - x0)^2, theta as in kind 6   params rows: k, x0
+ *   kind 8 shifted-periodic impropers (prior/harmonic.py:325-400)
+ *                                                          U = k (phi' - x0)^2, phi' = (phi < 0 ? phi + 2 pi : phi) - pi   rows: k, x0
+ *   mapping [order][n_terms] i64 global bead indices (order 2/3/2/4/4/3/3/3/4); params [n_params][n_terms] f32;
  *   bead_ptr [N+1] i64 and entries [order * n_terms] i32 = the CSR of the fixed topology by bead: entry =
  *   term << 2 | slot, the entries of bead b are bead_ptr[b]..bead_ptr[b+1] in ascending (term, slot) order
  *   (built once per topology by the caller; n_terms < 2^29).  ADDS the per-molecule energies to energy[n_mol]

@@ -5,6 +5,7 @@ The fixture holds inputs (positions, types, mappings, per-type parameter tables)
 
     python oracle/make_golden_priors.py          # case_priors.npz
     python oracle/make_golden_priors.py more     # case_priors_more.npz: HarmonicImpropers, QuarticAngles, RestrictedQuartic
+    python oracle/make_golden_priors.py unexported   # case_priors_unexported.npz: the two classes prior/__init__.py does not export
 
 ``more``: ``QuarticAngles`` (prior/polynomial.py:157-186) and ``RestrictedQuartic`` (prior/restricted_bending.py) run
 through their own ``forward``.  ``HarmonicImpropers.forward`` cannot run as written -- its ``data2features`` is declared
@@ -12,6 +13,11 @@ through their own ``forward``.  ``HarmonicImpropers.forward`` cannot run as writ
 TypeError -- and the fixture is made from the pieces of the class that do run: ``data2parameters`` (the per-type
 lookup), ``HarmonicImpropers.compute_features`` (= compute_torsions) and ``Harmonic.compute``, summed per molecule the
 way ``Harmonic.forward`` does (:109-113).
+
+``unexported``: ``ShiftedPeriodicHarmonicImpropers`` (prior/harmonic.py:325-400) through its own ``forward``.
+``HarmonicAnglesRaw`` (:264-298) cannot even be constructed as written (its ``__init__`` calls ``Harmonic.__init__`` without
+``order``: TypeError); its fixture is ``Harmonic(statistics, "raw_angles", order=3).data2parameters`` (the lookup),
+``HarmonicAnglesRaw.compute_features`` (= compute_angles_raw) and ``Harmonic.compute``.
 """
 import os
 import sys
@@ -135,5 +141,56 @@ def more():
     print("energies:", {k: out[f"{k}_energy_ref64"] for k in models})
 
 
+def unexported():
+    from flashmd.prior.harmonic import Harmonic, HarmonicAnglesRaw, ShiftedPeriodicHarmonicImpropers
+
+    n_mol, A, T = 3, 41, 5
+    pos, types, ptr = synthetic.chain_batch(n_mol, A, T)
+    topo = synthetic.chain_topology(n_mol, A)
+    g = torch.Generator().manual_seed(33)
+    r = lambda: torch.rand(1, generator=g, dtype=torch.float64)[0]  # noqa: E731
+    stats = {"raw_angles": {(a, b, c): {"k": 0.5 + 2 * r(), "x_0": 1.2 + 1.2 * r()}
+                            for a in range(T) for b in range(T) for c in range(T)},
+             "shifted_impropers": {(a, b, c, d): {"k": 0.5 + 2 * r(), "x_0": -1.0 + 2.0 * r()}
+                                   for a in range(T) for b in range(T) for c in range(T) for d in range(T)}}
+    mappings = {"raw_angles": topo["angles"], "shifted_impropers": topo["dihedrals"]}
+    try:
+        HarmonicAnglesRaw(stats["raw_angles"], "raw_angles")
+        raise AssertionError("HarmonicAnglesRaw can be constructed now: make the fixture from its forward")
+    except TypeError:
+        pass
+    models = {"raw_angles": Harmonic(stats["raw_angles"], "raw_angles", order=3),
+              "shifted_impropers": ShiftedPeriodicHarmonicImpropers(stats["shifted_impropers"])}
+    models["shifted_impropers"].name = "shifted_impropers"   # (the neighbour-list key; the class default is "impropers")
+    mol_of_bead = torch.arange(n_mol).repeat_interleave(A)
+    nl = {k: {"index_mapping": mappings[k], "mapping_batch": mol_of_bead[mappings[k][0]]} for k in mappings}
+    data = pytypes.SimpleNamespace(pos=pos.double().requires_grad_(True), atom_types=types, ptr=ptr, out={}, neighbor_list=nl)
+    out = {"pos": pos.numpy(), "types": types.numpy(), "ptr": ptr.numpy()}
+    total = 0
+    for k, m in models.items():
+        m = m.double()
+        if k == "raw_angles":
+            prm = m.data2parameters(data)
+            y = Harmonic.compute(HarmonicAnglesRaw.compute_features(data.pos, mappings[k]).flatten(), **prm)
+            e = torch.zeros(n_mol, dtype=torch.float64).index_add(0, nl[k]["mapping_batch"], y)
+        else:
+            data = m(data)
+            e = data.out[m.name]["energy"]
+        (gr,) = torch.autograd.grad(e.sum(), data.pos, retain_graph=True)
+        out[f"{k}_mapping"] = mappings[k].numpy()
+        out[f"{k}_energy_ref64"] = e.detach().numpy()
+        out[f"{k}_forces_ref64"] = (-gr).numpy()
+        total = total + e
+        for name, buf in m.named_buffers():
+            out[f"{k}_table_{name}"] = buf.numpy()
+    (gr,) = torch.autograd.grad(total.sum(), data.pos)
+    out["total_energy_ref64"] = total.detach().numpy()
+    out["total_forces_ref64"] = (-gr).numpy()
+    path = os.path.join(ROOT, "tests", "golden", "case_priors_unexported.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "energies:", {k: out[f"{k}_energy_ref64"] for k in models})
+
+
 if __name__ == "__main__":
-    more() if "more" in sys.argv[1:] else main()
+    arg = sys.argv[1:]
+    unexported() if "unexported" in arg else more() if "more" in arg else main()

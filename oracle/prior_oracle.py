@@ -63,6 +63,13 @@ def term_energies(kind, pos, mapping, params):
         return params[0] + (params[1:1 + n] * torch.sin(ang) + params[1 + n:] * torch.cos(ang)).sum(0)
     if kind == "impropers":
         return params[0] * (torsions(pos, mapping) - params[1]) ** 2           # k, x0
+    if kind == "raw_angles":        # prior/harmonic.py:264-298 (HarmonicAnglesRaw): k, x0 on the raw angle
+        return params[0] * (angles_raw(pos, mapping) - params[1]) ** 2
+    if kind == "shifted_impropers":  # prior/harmonic.py:325-400: torsions < 0 shifted by 2 pi, then pi subtracted
+        phi = torsions(pos, mapping)
+        pi32 = float(torch.tensor(torch.pi, dtype=torch.float32))   # the reference's torch_pi is a float32 tensor (harmonic.py:19)
+        phi = torch.where(phi < 0, phi + 2 * pi32, phi) - pi32
+        return params[0] * (phi - params[1]) ** 2
     if kind == "quartic_angles":                                               # v0, k_1 .. k_n
         x = angles_cos(pos, mapping)
         v, xp = params[1] * x, x
@@ -80,7 +87,7 @@ def term_energies(kind, pos, mapping, params):
 def lookup(kind, tables, types, mapping):
     """per-term parameters from per-type tables, as data2parameters does."""
     idx = tuple(types[mapping[i]] for i in range(mapping.shape[0]))
-    if kind in ("bonds", "angles", "impropers"):
+    if kind in ("bonds", "angles", "impropers", "raw_angles", "shifted_impropers"):
         return torch.stack([tables["k"][idx], tables["x_0"][idx]])
     if kind == "repulsion":
         return tables["sigma"][idx].unsqueeze(0)

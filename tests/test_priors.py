@@ -11,6 +11,7 @@ from oracle import prior_oracle as po
 
 KINDS = ("bonds", "angles", "repulsion", "dihedrals")
 MORE = ("impropers", "quartic_angles", "restricted_angles")   # case_priors_more.npz (make_golden_priors.py more)
+UNEXPORTED = ("raw_angles", "shifted_impropers")              # case_priors_unexported.npz (make_golden_priors.py unexported)
 
 
 def _load(golden_dir, name="case_priors.npz", kinds=KINDS):
@@ -77,6 +78,26 @@ def test_more_prior_kinds_oracle_and_host_mirror_match_reference_vectors(golden_
     assert _rel(both.energy_torch(pos.double(), ptr), sum(q.energy_torch(pos.double(), ptr) for q in parts)) < 1e-12
 
 
+def test_unexported_prior_classes_oracle_and_host_mirror(golden_dir):
+    """HarmonicAnglesRaw and ShiftedPeriodicHarmonicImpropers (in prior/harmonic.py, not exported by the package): oracle
+    and the host mirror's torch path against the reference's fp64 outputs.  Their buffers look like those of the angle /
+    improper classes, so a state_dict cannot tell them apart: they are reached through from_tables only."""
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir, "case_priors_unexported.npz", UNEXPORTED)
+    n_mol = ptr.numel() - 1
+    mol_of_bead = torch.repeat_interleave(torch.arange(n_mol), ptr[1:] - ptr[:-1])
+    for k in UNEXPORTED:
+        prm = po.lookup(k, tables[k], types, maps[k])
+        e, f = po.prior_energy_forces(pos.double(), [(k, maps[k], prm)], mol_of_bead, n_mol)
+        assert _rel(e, z[k + "_energy_ref64"]) < 1e-12 and _rel(f, z[k + "_forces_ref64"]) < 1e-11, k
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in UNEXPORTED}, types, ptr)
+    x = pos.double().requires_grad_(True)
+    e = sp.energy_torch(x, ptr)
+    (g,) = torch.autograd.grad(e.sum(), x)
+    assert _rel(e.detach(), z["total_energy_ref64"]) < 1e-6 and _rel(-g, z["total_forces_ref64"]) < 1e-6
+
+
 def test_prior_host_mirror_torch_path_matches_reference_vectors(golden_dir):
     """the plain-torch branch of the host mirror (what runs with --disable_optim / on the CPU)"""
     from flashmd_amd import prior
@@ -141,6 +162,24 @@ def test_more_prior_kinds_hip_vs_reference_vectors(golden_dir):
     sp = prior.StaticPriors.from_tables({k: (tables[k], big[k]) for k in MORE}, types, ptr).to(dev)
     e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
     assert _rel(e.cpu(), e_o) < 1e-5 and _rel(f.cpu(), f_o) < 3e-5
+
+
+@pytest.mark.gpu
+def test_unexported_prior_classes_hip_vs_reference_vectors(golden_dir):
+    """kinds 7 and 8 of fmd_prior_energy_forces against the reference's fp64 outputs"""
+    from flashmd_amd import prior
+
+    z, pos, types, ptr, tables, maps = _load(golden_dir, "case_priors_unexported.npz", UNEXPORTED)
+    dev = "cuda:0"
+    sp = prior.StaticPriors.from_tables({k: (tables[k], maps[k]) for k in UNEXPORTED}, types, ptr).to(dev)
+    e, f = sp.energy_forces(pos.to(dev), ptr.to(dev))
+    re, rf = _rel(e.cpu(), z["total_energy_ref64"]), _rel(f.cpu(), z["total_forces_ref64"])
+    print(f"raw angles + shifted impropers (HIP, fp32) vs reference fp64: energy {re:.2e} forces {rf:.2e}")
+    assert re < 1e-5 and rf < 3e-5
+    for k in UNEXPORTED:
+        one = prior.StaticPriors.from_tables({k: (tables[k], maps[k])}, types, ptr).to(dev)
+        ek, fk = one.energy_forces(pos.to(dev), ptr.to(dev))
+        assert _rel(ek.cpu(), z[k + "_energy_ref64"]) < 1e-5 and _rel(fk.cpu(), z[k + "_forces_ref64"]) < 3e-5, k
 
 
 @pytest.mark.gpu
