@@ -276,11 +276,15 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
           // DBS, step i (par = (i + 1) & 1): tile t+S is staged from the fragments in buffer `par` (written one step
           // ago), the fragments of t+2S go into the other buffer, whose last reader was the compute() of the step before
           if constexpr (DBS) frag_rd_buf = par ? frag_b1 : frag_b0;
+          if (!FMD_DBG_SKIP(a, 1)) {
           compute(t + 2 * S);  // tile t+S, while the consumers work on tile t ...
           if constexpr (DBS) gauss();   // tile t+2S (d_n holds its distances now)
+          }
           FMD_MARK(0)
+          if (!FMD_DBG_SKIP(a, 1)) {
           put_to(par ? hid_lo : hid_hi);  // ... into the plane they are not reading
           if constexpr (DBS) put_frags_to(par ? frag_b0 : frag_b1);
+          }
           FMD_MARK(2)
           tile_barrier();     // tile t+S visible, tile t consumed
           FMD_MARK(3)
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         // segment: the next segment's aggregate rows are requested, then the finished segment's registers take the new
         // offsets and its gathers are issued while that LDS read is in flight (a gather costs the CU's address unit
         // ~16 cycles, an LDS round trip ~100), then the next segment is finished, ...
-        {
+        if (!FMD_DBG_SKIP(a, 0)) {
           float vj[4], cval;
           auto seg_reads = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
         if (DB) fetch_meta(t + S);  // (the list registers are free once X is refilled; there is no B-A window in this form)
         // L1: filt slice = hidden . W1^T slice (lane = feature, registers = pairs)
         f32x16 acc1 = zero16();
-        {
+        if (!FMD_DBG_SKIP(a, 3)) {
           // fragments are read two k-steps ahead of their MFMAs; the fences keep the scheduler from
           // hoisting all sixteen 16-byte reads (64 registers) to the top of the loop
           // (W16A16: no low plane -- in the double-buffered form hid_lo is the OTHER tile, which the producers are writing)
