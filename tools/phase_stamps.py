@@ -46,7 +46,7 @@ lib.fmd_debug_set_stamps(None, -1, 0, 0)
 st = eng.status.tolist()
 tiles_per_wg = (st[2] / args.batch * 1.008 / 32) / (n_wg / args.batch)   # pairs + ~0.8 % pad entries (tools/pad_stats.py)
 t = buf.view(n_wg, 16, NST).double().cpu()   # 16 wave slots per workgroup (the forward kernel runs 12 waves)
-groups = [("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8)), ("waves 8-11", slice(8, 12))]
+groups = [("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8)), ("waves 8-11", slice(8, 12)), ("waves 12-15", slice(12, 16))]
 for name, sl in groups:
     if t[:, sl].sum() == 0:
         continue
