@@ -462,27 +462,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) X.xj[4 * q + e] = *reinterpret_cast<const float*>(x1b + X.oj[4 * q + e]);
           };
-#ifdef FMD_EXP_HOIST
-          // EXPERIMENT (timing only, wrong sums where rows recur inside a tile): every aggregate row of the tile is read
-          // up front -- what the update would cost if its four LDS round trips did not depend on one another
-          float vj4[16], cv4[4];
-          static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vj4[4 * q + e] = agg_rd(X.oj[4 * q + e]);
-            cv4[q] = agg_rd(X.oi[q]);
-          });
-          static_for<0, 4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vj[e] = vj4[4 * q + e];
-            cval = cv4[q];
-            seg_finish(qc);
-            __builtin_amdgcn_sched_barrier(0);
-            seg_refill(qc);
-            __builtin_amdgcn_sched_barrier(0);
-          });
-#else
           seg_reads(std::integral_constant<int, 0>{});
           static_for<0, 4>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -493,7 +472,6 @@ __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
             seg_refill(qc);
             __builtin_amdgcn_sched_barrier(0);
           });
-#endif
         }
         FMD_MARK(0)
         if (DB) fetch_meta(t + S);  // (the list registers are free once X is refilled; there is no B-A window in this form)

@@ -205,7 +205,7 @@ class FusedSchNetEngine:
             # (a fixed ceiling, and never more than half of what the device has free right now, the current workspace --
             # about to be released -- counted as free; an allocation that fails all the same is retried once without)
             self.desc.flags = self._flags
-            self._ws = None
+            self._ws, self._ws_key = None, None   # (a failed allocation must leave the engine able to allocate again)
             wants_stash = self.desc.precision == PRECISIONS["f32"] and not (self._flags & _ffi.FLAG_NO_FILTER_STASH)
             stash = (self.desc.num_blocks - 1) * n_mol * cap * 512
             # (free = what the driver reports plus what torch's caching allocator holds unused: the old workspace is there)

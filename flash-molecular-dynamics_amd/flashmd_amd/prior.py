@@ -148,7 +148,11 @@ def _lookup(kind: str, tables: Dict[str, torch.Tensor], types, mapping):
                      + [tables["k2s"][i][idx].unsqueeze(0) for i in range(n)])
 
 
-def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Tensor]]]:
+# kinds whose buffers look the same in a state_dict: the file alone cannot tell them apart
+_AMBIGUOUS = {"angles": ("angles", "raw_angles"), "impropers": ("impropers", "shifted_impropers")}
+
+
+def prior_tables_from_state_dict(sd, kinds: Dict[str, str] = None) -> Dict[str, Tuple[str, Dict[str, torch.Tensor]]]:
     """The prior models of a reference-format container, read from its ``state_dict``: name -> (kind, per-type tables).
     The reference's prior classes keep their parameters as BUFFERS indexed by bead types: ``Harmonic.x_0`` / ``.k``
     (prior/harmonic.py:60-77; order 2 = bonds, order 3 = angles), ``Repulsion.sigma`` (prior/repulsion.py:52-60),
@@ -157,7 +161,16 @@ def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Ten
     ``RestrictedQuartic.a`` .. ``.d`` / ``.k`` / ``.v_0`` (prior/restricted_bending.py:68-88), each under
     ``<prefix>.<name>.model.`` in ``SumOut.models`` (models/gradients.py:64-69).  The kind is told by the buffer set and
     its rank, the name is the ModuleDict key -- the key of ``data.neighbor_list`` the term's index mapping lives
-    under.  The topology itself is not in the file: ``StaticPriors.from_state_dict`` takes it from the caller."""
+    under.  The topology itself is not in the file: ``StaticPriors.from_state_dict`` takes it from the caller.
+
+    AMBIGUITY: ``HarmonicAnglesRaw`` (harmonic in theta, prior/harmonic.py:264-298) keeps the same ``x_0`` / ``k`` buffers
+    of rank 3 as ``HarmonicAngles`` (harmonic in cos theta), and ``ShiftedPeriodicHarmonicImpropers`` (:325-400) the same
+    rank-4 pair as ``HarmonicImpropers``; the class is not in a ``state_dict``.  The default reading is the exported one
+    (``angles``, ``impropers``); ``kinds={name: "raw_angles"}`` (or ``"shifted_impropers"``) overrides it per prior name.
+    A rank-3 ``x_0`` outside [-1, 1] cannot be a cosine: that table raises unless the caller has said what it is."""
+    import warnings
+
+    kinds = dict(kinds or {})
     groups: Dict[str, Dict[str, torch.Tensor]] = {}
     for key, v in sd.items():
         head, _, leaf = key.rpartition(".")
@@ -185,7 +198,23 @@ def prior_tables_from_state_dict(sd) -> Dict[str, Tuple[str, Dict[str, torch.Ten
         else:
             raise ValueError(f"state_dict entry {head!r} looks like a prior ({sorted(names)}, rank "
                              f"{[int(b.dim()) for b in bufs.values()]}) of a kind this build does not evaluate")
+        if name in kinds:
+            want = kinds.pop(name)
+            if want not in _AMBIGUOUS.get(kind, (kind,)):
+                raise ValueError(f"prior {name!r} has the buffers of {_AMBIGUOUS.get(kind, (kind,))}, not of {want!r}")
+            kind = want
+        elif kind == "angles":
+            x0 = bufs["x_0"][bufs["k"] != 0] if bufs["k"].shape == bufs["x_0"].shape else bufs["x_0"]
+            if x0.numel() and float(x0.abs().max()) > 1.0 + 1e-6:
+                raise ValueError(f"prior {name!r}: x_0 reaches {float(x0.abs().max()):.3f}, which cannot be a cosine -- "
+                                 "a HarmonicAnglesRaw table?  Pass kinds={%r: 'raw_angles'} (or 'angles' to insist)" % name)
+        elif kind == "impropers":
+            warnings.warn(f"prior {name!r}: rank-4 Harmonic buffers are read as HarmonicImpropers; a "
+                          "ShiftedPeriodicHarmonicImpropers model has the same buffers -- pass "
+                          "kinds={%r: 'shifted_impropers'} if that is what the file holds" % name, stacklevel=2)
         out[name] = (kind, bufs)
+    if kinds:
+        raise KeyError(f"kinds names priors the state_dict does not hold: {sorted(kinds)}")
     return out
 
 
@@ -250,19 +279,21 @@ class StaticPriors:
         return cls(terms, int((mol_ptr[1:] - mol_ptr[:-1]).max()))
 
     @classmethod
-    def from_state_dict(cls, sd, topology: Dict[str, torch.Tensor], types, mol_ptr):
+    def from_state_dict(cls, sd, topology: Dict[str, torch.Tensor], types, mol_ptr, kinds: Dict[str, str] = None):
         """Row N4: the condensed priors of a reference-format ``SumOut`` container (what
         ``condense_all_priors_for_simulation`` builds from the model, simulation/specialize_prior.py:76-207) from its
         ``state_dict`` -- a dict, an ``.npz`` or a weights-only ``torch.load`` file -- plus the index mappings
         ``topology[name]`` [order, M] (global bead indices of the collated batch: ``data.neighbor_list[name]
         ["index_mapping"]``), bead types [N] and mol_ptr [B+1] on the CPU.  Every prior in the file needs its mapping;
         several priors of one kind (two bond models under different names, ...) are condensed into one term list as the
-        reference does (``from_tables``)."""
+        reference does (``from_tables``).  ``kinds``: per prior name, which of two classes with identical buffers the
+        file holds (``raw_angles`` for HarmonicAnglesRaw, ``shifted_impropers`` for ShiftedPeriodicHarmonicImpropers):
+        see ``prior_tables_from_state_dict``."""
         if isinstance(sd, str):
             from .schnet import _state_dict_from_file
 
             sd = _state_dict_from_file(sd)
-        found = prior_tables_from_state_dict(sd)
+        found = prior_tables_from_state_dict(sd, kinds)
         spec = {}
         for name, (kind, tables) in found.items():
             if name not in topology:

@@ -382,7 +382,7 @@ class TrajectoryWriter:
 
 
 def force_fn_from_state_dict(sd, atom_types, mol_ptr, topology=None, device="cuda", max_beads_per_mol: int = 0,
-                             cutoff: Optional[float] = None, **engine_kw):
+                             cutoff: Optional[float] = None, prior_kinds=None, **engine_kw):
     """Row N4: the force provider of a reference-format model file.  ``sd``: the ``state_dict`` of the reference's
     ``SumOut{SchNet: GradientsOut(StandardSchNet), <prior name>: GradientsOut(<prior>) ...}`` container
     (models/gradients.py:19-152; a dict, an ``.npz``, or a weights-only ``torch.load`` file -- never the pickled
@@ -390,7 +390,9 @@ def force_fn_from_state_dict(sd, atom_types, mol_ptr, topology=None, device="cud
     fused SchNet engine + condensed priors (``prior.sum_out``), with ``check_status``; ``force_fn.engine`` and
     ``force_fn.priors`` expose the parts.  ``topology``: prior name -> index mapping [order, M] of the collated batch
     (needed when the file holds priors: a state_dict does not carry the topology); ``atom_types`` [N], ``mol_ptr`` [B+1]
-    (CPU or device).  Hyper-parameters the weights do not encode: see ``schnet.model_from_state_dict``."""
+    (CPU or device).  Hyper-parameters the weights do not encode: see ``schnet.model_from_state_dict``.
+    ``prior_kinds``: prior name -> ``"raw_angles"`` / ``"shifted_impropers"`` for the two classes whose buffers a
+    state_dict cannot tell from ``HarmonicAngles`` / ``HarmonicImpropers`` (``prior.prior_tables_from_state_dict``)."""
     from . import engine as _engine
     from . import prior as _prior
     from .schnet import _state_dict_from_file
@@ -407,8 +409,9 @@ def force_fn_from_state_dict(sd, atom_types, mol_ptr, topology=None, device="cud
     schnet_fn.check_status = eng.check_status
     parts = [schnet_fn]
     priors = None
-    if _prior.prior_tables_from_state_dict(sd):
-        priors = _prior.StaticPriors.from_state_dict(sd, topology or {}, atom_types.cpu(), mol_ptr.cpu()).to(device)
+    if _prior.prior_tables_from_state_dict(sd, prior_kinds):
+        priors = _prior.StaticPriors.from_state_dict(sd, topology or {}, atom_types.cpu(), mol_ptr.cpu(),
+                                                     kinds=prior_kinds).to(device)
         parts.append((priors, ptr_d))
     fn = _prior.sum_out(parts)
     fn.engine, fn.priors = eng, priors

@@ -244,7 +244,10 @@ def test_bench_launches_its_own_ranks():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line == {"launch_check": True, "n_gpus": 2, "rank_sum": 1, "gpus_arg": 2}
+    assert {k: line[k] for k in ("launch_check", "n_gpus", "rank_sum", "gpus_arg")} == \
+        {"launch_check": True, "n_gpus": 2, "rank_sum": 1, "gpus_arg": 2}
+    # every rank reports who it is (on a GPU run: PCI bus id / UUID of its device, `devices` on the bench line)
+    assert sorted(d["rank"] for d in line["devices"]) == [0, 1] and line["distinct_processes"] == 2
 
 
 @pytest.mark.parametrize("extra", [[], ["--pt"]])
@@ -264,7 +267,11 @@ def test_bench_launch_path_with_eight_ranks(extra):
                           *extra], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line == {"launch_check": True, "n_gpus": 8, "rank_sum": 28, "gpus_arg": 8}
+    assert {k: line[k] for k in ("launch_check", "n_gpus", "rank_sum", "gpus_arg")} == \
+        {"launch_check": True, "n_gpus": 8, "rank_sum": 28, "gpus_arg": 8}
+    # the keys the first 8-GPU run will carry: one identity record per rank, gathered over the process group
+    assert sorted(d["rank"] for d in line["devices"]) == list(range(8)) and line["distinct_processes"] == 8
+    assert all(set(d) >= {"rank", "local_rank", "host", "pid", "name", "uuid", "pci_bus_id"} for d in line["devices"])
 
 
 def test_bench_exchange_attempts_fall_inside_a_short_timed_region():

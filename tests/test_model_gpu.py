@@ -895,6 +895,55 @@ def test_queue_mode_many_small_molecules(params, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "w16a16"])
+@pytest.mark.parametrize("n_mol,num_rbf", [(384, 50), (300, 100)])
+def test_queue_mode_with_split_items_and_wide_basis(params, precision, n_mol, num_rbf):
+    """queue mode beyond its first test's S = 1.  384 molecules on 256 CUs: resolve_split cuts every molecule
+    into S = 2 pieces (items q = m S + s, two slabs per molecule, grid (1, CUs) with n_split = 1 in the kernel's
+    arguments); 300 molecules with 100 Gaussians: the queue with the per-wave Gaussian instantiations (NS0 = 8).  The
+    default engine must equal the plain launch with the same split given by the caller (no queue) bit for bit, repeat
+    itself bit for bit, and meet the fp64 oracle on a few molecules."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    p = params if num_rbf == 50 else so.make_params(num_rbf=num_rbf, num_interactions=2, out_widths=(64,), seed=3,
+                                                    bias_scale=0.1)
+    g = torch.Generator().manual_seed(11)
+    sizes = torch.randint(20, 81, (n_mol,), generator=g).tolist()
+    parts = [so.synth_batch(1, n, 5.0, first_mol=k) for k, n in enumerate(sizes)]
+    pos = torch.cat([q[0] for q in parts])
+    types = torch.cat([q[1] for q in parts])
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    model = S.model_from_params(p).to(DEV)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    # the split the library chooses for more molecules than CUs (fmd_engine_host.hip resolve_split)
+    best, best_t = 1, 1e30
+    for sp in range(1, 5):
+        t = ((n_mol * sp + cus - 1) // cus) / sp * (1.0 + 0.04 * (sp - 1))
+        if t < best_t - 1e-9:
+            best, best_t = sp, t
+    queued = engine.FusedSchNetEngine(model, precision=precision)
+    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=best)
+    e, f = queued.energy_forces(P, T, Q, 80)
+    queued.check_status()
+    e1, f1 = plain.energy_forces(P, T, Q, 80)
+    plain.check_status()
+    assert torch.isfinite(f).all() and torch.equal(e, e1) and torch.equal(f, f1), f"split {best}"
+    e2, f2 = queued.energy_forces(P, T, Q, 80)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    pick = [0, 1, cus - 1, cus, n_mol - 1]
+    sel = torch.cat([torch.arange(int(ptr[m]), int(ptr[m + 1])) for m in pick])
+    ptr_s = torch.tensor([0] + list(np.cumsum([sizes[m] for m in pick])), dtype=torch.int64)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(p, torch.float64), pos[sel].double(), types[sel], ptr_s)
+    re, rf = _relerr(e.cpu()[pick], f.cpu()[sel], e_o.numpy(), f_o.numpy())
+    print(f"queue mode, {n_mol} molecules, split {best}, R = {num_rbf}, {precision}: energy {re:.2e} forces {rf:.2e}")
+    tol = 5e-3 if precision == "w16a16" else 2e-5
+    assert re < tol and rf < tol
+    if n_mol == 384 and cus == 256:
+        assert best == 2
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
 @pytest.mark.parametrize("num_rbf", [65, 100, 128])
 def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
     """Engine envelope, round 5: a Gaussian basis of 65..128 functions (StandardSchNet takes any, reference

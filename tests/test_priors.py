@@ -96,6 +96,25 @@ def test_unexported_prior_classes_oracle_and_host_mirror(golden_dir):
     e = sp.energy_torch(x, ptr)
     (g,) = torch.autograd.grad(e.sum(), x)
     assert _rel(e.detach(), z["total_energy_ref64"]) < 1e-6 and _rel(-g, z["total_forces_ref64"]) < 1e-6
+    # ... and through the state_dict loader with the caller saying which class the ambiguous buffers belong to
+    sd = {f"models.{k}.model.{n}": t for k in UNEXPORTED for n, t in tables[k].items()}
+    kinds = {"raw_angles": "raw_angles", "shifted_impropers": "shifted_impropers"}
+    found = prior.prior_tables_from_state_dict(sd, kinds)
+    assert {k: v[0] for k, v in found.items()} == kinds
+    sp2 = prior.StaticPriors.from_state_dict(sd, maps, types, ptr, kinds=kinds)
+    assert _rel(sp2.energy_torch(pos.double(), ptr), z["total_energy_ref64"]) < 1e-6
+    # without the override the raw-angle table (equilibrium angles in radians, beyond 1) is refused, not read as cosines,
+    # and the rank-4 pair is read as the exported class with a warning
+    assert float(tables["raw_angles"]["x_0"].abs().max()) > 1.0
+    with pytest.raises(ValueError, match="cannot be a cosine"):
+        prior.prior_tables_from_state_dict({k: v for k, v in sd.items() if ".raw_angles." in k})
+    with pytest.warns(UserWarning, match="ShiftedPeriodicHarmonicImpropers"):
+        got = prior.prior_tables_from_state_dict({k: v for k, v in sd.items() if ".shifted_impropers." in k})
+    assert got["shifted_impropers"][0] == "impropers"
+    with pytest.raises(ValueError):
+        prior.prior_tables_from_state_dict(sd, {"raw_angles": "bonds", "shifted_impropers": "shifted_impropers"})
+    with pytest.raises(KeyError):
+        prior.prior_tables_from_state_dict(sd, dict(kinds, nobody="raw_angles"))
 
 
 def test_prior_host_mirror_torch_path_matches_reference_vectors(golden_dir):

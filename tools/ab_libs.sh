@@ -4,6 +4,7 @@
 # the original comes back)
 LIB=flash-molecular-dynamics_amd/flashmd_amd/libflashmd_hip.so
 cp $LIB /tmp/lib_orig.so
+trap 'cp /tmp/lib_orig.so $LIB' EXIT   # whatever happens in between, the in-tree library comes back
 for pass in $(seq 1 ${PASSES:-2}); do
   for v in "$@"; do
     cp $v $LIB

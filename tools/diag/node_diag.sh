@@ -1,9 +1,7 @@
-# node-kernel diagnostic variants (gpurun_ab/nd_K.so: bit 0 = no global stores, bit 1 = row loads from 8 cached tiles): per-launch times
-LIB=flash-molecular-dynamics_amd/flashmd_amd/libflashmd_hip.so
-cp $LIB /tmp/lib_keep.so
+# node-kernel diagnostic variants (gpurun_ab/nd_K.so from tools/diag/node_diag_build.sh: bit 0 = no global stores, bit 1 = row
+# loads from 8 cached tiles -- WRONG results, timing only): per-launch times.  The variants are loaded through FMD_DIAG_LIB
+# (tools/slot_times.py); the product library is never overwritten.
 for v in 0 1 2 3 0; do
-  cp gpurun_ab/nd_$v.so $LIB
   echo "== nd_$v"
-  timeout -k 10 200 python tools/slot_times.py --reps 20 2>&1 | grep -E "node_|embed|sum"
+  FMD_DIAG_LIB=gpurun_ab/nd_$v.so timeout -k 10 200 python tools/slot_times.py --reps 20 2>&1 | grep -E "node_|embed|sum"
 done
-cp /tmp/lib_keep.so $LIB

@@ -5,6 +5,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "flash-molecular-dynamics_amd")]
 from bench import HipEvents
+from flashmd_amd import _ffi
+if os.environ.get("FMD_DIAG_LIB"):   # a diagnostic build of the library (tools/diag/*.sh): this tool only, never the package
+    _ffi.LIB_PATH = os.path.abspath(os.environ["FMD_DIAG_LIB"])
 from flashmd_amd import engine, synthetic
 import flashmd_amd.schnet as S
 
