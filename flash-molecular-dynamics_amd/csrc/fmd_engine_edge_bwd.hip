@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
   // 65..128 Gaussians (NS0 = 8): every producer forms the Gaussians of its own pairs (the shared form deals ONE k-step to
   // each of four waves, and its centre-weighted operand would not fit the register file next to eight k-steps of W0)
-  static_assert(NS0 <= 4 || (!SHARE && !FS), "NS0 = 8 runs in the per-wave Gaussian form, whole-aggregate mode");
+  static_assert(NS0 <= 4 || !SHARE, "NS0 = 8 runs in the per-wave Gaussian form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
@@ -748,14 +748,19 @@ namespace fmd_eng {
   M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
   M_(false, true, true, true, false, false) M_(false, false, true, true, false, false)         \
   M_(false, true, true, true, true, false) M_(false, false, true, true, true, false)
-// NS0 = 8 (65..128 Gaussians): the per-wave Gaussian form in whole-aggregate mode only
+// NS0 = 8 (65..128 Gaussians): the per-wave Gaussian form; round 6: also in feature-split mode (284..535 beads)
 #define FMD_BWD_WIDE_F32(M_)                                                                    \
   M_(true, true, false, false, false, false) M_(true, false, false, false, false, false)       \
   M_(true, true, false, false, false, true) M_(true, false, false, false, false, true)         \
-  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)
+  M_(false, true, false, false, false, false) M_(false, false, false, false, false, false)     \
+  M_(true, true, false, false, true, false) M_(true, false, false, false, true, false)         \
+  M_(true, true, false, false, true, true) M_(true, false, false, false, true, true)           \
+  M_(false, true, false, false, true, false) M_(false, false, false, false, true, false)
 #define FMD_BWD_WIDE_HALF(M_)                                                                   \
   M_(true, true, false, true, false, false) M_(true, false, false, true, false, false)         \
-  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)
+  M_(false, true, false, true, false, false) M_(false, false, false, true, false, false)       \
+  M_(true, true, false, true, true, false) M_(true, false, false, true, true, false)           \
+  M_(false, true, false, true, true, false) M_(false, false, false, true, true, false)
 #ifdef FMD_HALF_TU   // this translation unit: the W16A16 kernels, reached through the *_half entry points
 #define FMD_TU(x) x##_half
 #define FMD_BWD_MINE(M_) if constexpr (NS0 > 4) { FMD_BWD_WIDE_HALF(M_) } else { FMD_BWD_HALF(M_) FMD_BWD_B0_HALF(M_) }
@@ -801,9 +806,9 @@ static int launch_bwd(const EdgeArgs& a, bool half, bool need, bool first, dim3 
                                    (a.fs ? 0 : frag + (size_t)(4096 + 128) * sizeof(float));
   const bool share = NS0 <= 4 && lds_sh <= MAX_LDS_BYTES;
   const bool stash = need && !half && a.wst != nullptr;
-  if (lds > MAX_LDS_BYTES || (a.fs && !share)) return FMD_EUNSUPPORTED;  // feature-split mode always shares
+  if (lds > MAX_LDS_BYTES || (a.fs && !share && NS0 <= 4)) return FMD_EUNSUPPORTED;  // up to 64 Gaussians feature-split mode always shares
 #define FMD_ONE(N_, F_, S_, H_, FS_, ST_)                                                                  \
-  if (need == N_ && first == F_ && (share || a.fs) == S_ && half == H_ && a.fs == FS_ && stash == ST_) {  \
+  if (need == N_ && first == F_ && (share || (a.fs && NS0 <= 4)) == S_ && half == H_ && a.fs == FS_ && stash == ST_) {  \
     edge_bwd_split_kernel<NS0, N_, F_, S_, H_, FS_, ST_><<<grid, 512, (S_) ? lds_sh : lds, s>>>(a);      \
     return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;                                         \
   }

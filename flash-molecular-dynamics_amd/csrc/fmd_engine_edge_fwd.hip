@@ -42,7 +42,7 @@ struct SegRegs {              // consumer state of one 32-entry tile, register r
 template <int NS0, bool HALF, bool FS, bool SH, bool STASH>  // NS0: k-steps of 16 covering the rbf index; HALF: W16A16
 __global__ __launch_bounds__(512, 2) void edge_fwd_split_kernel(EdgeArgs a) {
   static_assert(!(HALF && STASH), "the filter stash is an fp32-grade form");
-  static_assert(NS0 <= 4 || (!SH && !FS), "NS0 = 8 runs in the per-wave Gaussian form, whole-aggregate mode");
+  static_assert(NS0 <= 4 || !SH, "NS0 = 8 runs in the per-wave Gaussian form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   _Float16* hid_hi = reinterpret_cast<_Float16*>(smem);          // [32][LDH]
   _Float16* hid_lo = hid_hi + 32 * LDH;                          // [32][LDH]
@@ -574,11 +574,11 @@ int launch_edge_fwd_half(const EdgeArgs& a, int num_rbf, bool half, int64_t n_mo
 #define FMD_FWD_MINE(M_)                                          \
   if constexpr (TU_HALF) {                                        \
     if constexpr (!STASH) {                                       \
-      if constexpr (NS0 > 4) { M_(true, false, false) }           \
+      if constexpr (NS0 > 4) { M_(true, false, false) M_(true, true, false) }           \
       else { FMD_FWD_HALF(M_) }                                   \
     }                                                             \
   } else if constexpr (NS0 > 4) {                                 \
-    M_(false, false, false) /* 65..128 Gaussians: per-wave Gaussian form, whole-aggregate mode */ \
+    M_(false, false, false) M_(false, true, false) /* 65..128 Gaussians: per-wave Gaussian form */ \
   } else {                                                        \
     FMD_FWD_F32(M_)                                               \
   }
@@ -614,7 +614,7 @@ static int launch_fwd(const EdgeArgs& a, bool half, dim3 grid, hipStream_t s) {
   // W16A16: [tile region = two hidden planes][two fragment buffers of nb x 512 B][aggregate rows] (the same size)
   const size_t lds_sh = (size_t)(TILE_FLOATS + 128 + a.nb * 256 + a.max_beads * F) * sizeof(float);
   const bool sh = NS0 <= 4 && !a.fs && lds_sh <= MAX_LDS_BYTES;
-  if (lds > MAX_LDS_BYTES || (NS0 > 4 && a.fs)) return FMD_EUNSUPPORTED;
+  if (lds > MAX_LDS_BYTES) return FMD_EUNSUPPORTED;
 #define FMD_ONE(H_, FS_, SH_)                                                                     \
   if (half == H_ && a.fs == FS_ && sh == SH_) {                                                   \
     edge_fwd_split_kernel<NS0, H_, FS_, SH_, STASH><<<grid, 512, (SH_) ? lds_sh : lds, s>>>(a);  \

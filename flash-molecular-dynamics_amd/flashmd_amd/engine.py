@@ -4,7 +4,7 @@
 Replaces, for qualifying models, what the reference does per timestep in SchNet.forward +
 GradientsOut.forward (reference models/schnet.py:178-369, models/gradients.py:226-290).  A model
 qualifies when it has the StandardSchNet shape the kernels are built for: Gaussian basis with
-<= 128 functions (above 64: molecules up to 283 beads), cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
+<= 128 functions, cosine cutoff with lower bound 0 used for both the basis and the CFConv envelope,
 tanh, hidden <= 128 and filters <= 128 (the kernels are built for 128 x 128: narrower layers are zero-padded when the
 weights are packed, which is exact -- a padded feature is 0 in every layer -- and costs the padded arithmetic), a 2- or
 3-linear output MLP with widths <= 128, fp32 weights (or the W16A16 twins of models/gptq.py on both the filter and
@@ -24,7 +24,7 @@ from ._ffi import call, ptr, stream
 
 MAX_BEADS = 535   # 283 with the whole aggregate in one workgroup's LDS, 535 in feature-split mode
 MAX_BEADS_WHOLE = 283
-MAX_RBF = 128     # csrc/fmd_engine.h MAX_RBF; 65..128 Gaussians run in whole-aggregate mode only (no feature split)
+MAX_RBF = 128     # csrc/fmd_engine.h MAX_RBF; 65..128 Gaussians run in the per-wave Gaussian form (round 6: feature-split mode too)
 # fmd_schnet_desc.precision (include/flashmd_hip.h)
 PRECISIONS = {"f32": 0,        # FMD_PREC_F32: split-operand f16 MFMA, fp32-grade (2e-7 per contraction), the default
               "w16a16": 1}     # FMD_PREC_W16A16: filter and output networks with fp16 operands, fp32 accumulate
@@ -131,8 +131,8 @@ class FusedSchNetEngine:
 
         self.device = model.embedding_layer.weight.device
         self.cutoff = float(rbf.cutoff.cutoff_upper)
-        # the largest molecule this engine takes: a basis of 65..128 Gaussians has no feature-split mode
-        self.max_beads = MAX_BEADS if rbf.num_rbf <= 64 else MAX_BEADS_WHOLE
+        # the largest molecule this engine takes (round 6: a basis of 65..128 Gaussians has a feature-split mode as well)
+        self.max_beads = MAX_BEADS
         d = _ffi.SchnetDesc()
         d.hidden, d.num_rbf, d.num_blocks, d.num_out = 128, rbf.num_rbf, len(blocks), len(outs)
         for k in range(4):

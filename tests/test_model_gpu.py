@@ -948,9 +948,10 @@ def test_queue_mode_with_split_items_and_wide_basis(params, precision, n_mol, nu
 def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
     """Engine envelope, round 5: a Gaussian basis of 65..128 functions (StandardSchNet takes any, reference
     models/schnet.py:778-841, radial_basis/gaussian.py:33-75) runs on the engine -- eight k-steps of filter layer 0, every
-    producer forming the Gaussians of its own pairs, whole-aggregate mode (<= 283 beads).  Against the fp64 oracle of the
-    same random model: a ragged batch incl. a 269-bead molecule; stash form (fp32) equal to recomputation; repeat calls
-    bit-identical; a 300-bead molecule is declined (operator path) instead of mis-handled."""
+    producer forming the Gaussians of its own pairs.  Against the fp64 oracle of the same random model: a ragged batch
+    incl. a 269-bead molecule; stash form (fp32) equal to recomputation; repeat calls bit-identical.  Round 6: the same
+    for molecules of 400 and 300 beads in feature-split mode (two workgroups per molecule, 64 features each), which such
+    a model had to leave to the operator path."""
     import flashmd_amd.schnet as S
     from flashmd_amd import engine
 
@@ -962,7 +963,7 @@ def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
     e_o, f_o = so.schnet_energy_forces(so.params_to(p, torch.float64), pos.double(), types, ptr)
     model = S.model_from_params(p).to(DEV)
     eng = engine.FusedSchNetEngine(model, precision=precision)
-    assert eng.max_beads == 283
+    assert eng.max_beads == 535
     P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
     e, f = eng.energy_forces(P, T, Q, 269)
     eng.check_status()
@@ -976,14 +977,31 @@ def test_wide_basis_up_to_128_gaussians(num_rbf, precision):
         plain = engine.FusedSchNetEngine(model, filter_stash=False)
         e3, f3 = plain.energy_forces(P, T, Q, 269)
         assert torch.equal(e, e3) and torch.equal(f, f3)
-        # through the reference-shaped entry: the engine answers; a 300-bead molecule goes to the operator path
+        # through the reference-shaped entry: the engine answers
         e4, f4 = _run(S, p, pos, types, ptr, engine=True)
         assert torch.equal(e4.to(DEV), e) and torch.equal(f4.to(DEV), f)
-        big = so.synth_batch(1, 300, 5.0)
-        data = S.Batch(big[0].to(DEV), big[1].to(DEV), big[2].to(DEV))
-        assert engine.maybe_engine(model, data) is None
-        with pytest.raises(RuntimeError):
-            eng.energy_forces(big[0].to(DEV), big[1].to(DEV), big[2].to(DEV), 300)
+    # round 6: molecules of 284..535 beads run in feature-split mode with this basis too (they took the operator path)
+    parts = [so.synth_batch(1, n, 5.0, first_mol=31 + n) for n in (400, 300)]
+    posb = torch.cat([q[0] for q in parts])
+    typesb = torch.cat([q[1] for q in parts])
+    ptrb = torch.tensor([0, 400, 700], dtype=torch.int64)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(p, torch.float64), posb.double(), typesb, ptrb)
+    data = S.Batch(posb.to(DEV), typesb.to(DEV), ptrb.to(DEV))
+    assert engine.maybe_engine(S.model_from_params(p).to(DEV), data) is not None
+    eb, fb = eng.energy_forces(posb.to(DEV), typesb.to(DEV), ptrb.to(DEV), 400)
+    eng.check_status()
+    re, rf = _relerr(eb, fb, e_o.numpy(), f_o.numpy())
+    print(f"R = {num_rbf} {precision}, 400 + 300 beads (feature-split mode): energy {re:.2e} forces {rf:.2e} vs the fp64 oracle")
+    assert re < tol and rf < tol
+    eb2, fb2 = eng.energy_forces(posb.to(DEV), typesb.to(DEV), ptrb.to(DEV), 400)
+    assert torch.equal(eb, eb2) and torch.equal(fb, fb2)
+    if precision == "f32":
+        plain = engine.FusedSchNetEngine(model, filter_stash=False)
+        eb3, fb3 = plain.energy_forces(posb.to(DEV), typesb.to(DEV), ptrb.to(DEV), 400)
+        assert torch.equal(eb, eb3) and torch.equal(fb, fb3)
+    with pytest.raises(RuntimeError):   # above 535 beads no engine mode holds the aggregate
+        big = so.synth_batch(1, 540, 5.0)
+        eng.energy_forces(big[0].to(DEV), big[1].to(DEV), big[2].to(DEV), 540)
 
 
 @pytest.mark.parametrize("shape", ["8x269", "ragged", "fs_2x400"])
