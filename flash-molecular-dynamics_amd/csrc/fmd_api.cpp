@@ -13,4 +13,4 @@ extern "C" const char* fmd_strerror(int code) {
   }
 }
 
-extern "C" int fmd_abi_version(void) { return 5; }
+extern "C" int fmd_abi_version(void) { return 6; }

@@ -73,6 +73,23 @@ constexpr int SLICE = 2 * Q1_FLOATS;        // floats of one packed 128x128 node
 constexpr int ITEM_INTS = 8;
 constexpr int WST_TILE_FLOATS = 32 * F;     // one tile of the filter stash (EdgeArgs::wst): 32 entries x 128 features
 
+// Molecule GROUPS (round 6).  Every engine kernel that walks "a molecule" -- its pair list, its aggregate in LDS, its work
+// items -- really walks a group of `mol_stride` consecutive molecules of the batch: group g = molecules [g stride,
+// (g + 1) stride), beads [mol_ptr[g stride], mol_ptr[(g + 1) stride]).  stride = 1 is the plain case.  Batches of many
+// small molecules run with stride > 1 (run_engine): a 10-bead molecule is 45 pairs = two tiles, and one workgroup item,
+// one aggregate staging and one pairs_kernel workgroup of 1024 threads per such molecule was all fixed cost.  Rows of
+// different molecules of a group never meet in a pair (pairs_kernel tests the molecule index), so the group's pair list is
+// block diagonal and everything downstream is unchanged.
+struct MolView {
+  const int64_t* ptr;      // the batch's mol_ptr [n_mol_real + 1]
+  int64_t n_real;          // molecules of the batch
+  int stride;              // molecules per group
+};
+__device__ __forceinline__ int64_t grp_begin(const MolView& v, int64_t g) {
+  const int64_t m = g * v.stride;
+  return v.ptr[m < v.n_real ? m : v.n_real];
+}
+
 struct EdgeArgs {
   const int* items;        // [n_mol * n_split][2][ITEM_INTS]
   const uint32_t* poi;     // centre row byte offsets (i * 512)
@@ -84,7 +101,7 @@ struct EdgeArgs {
   int64_t pgd_stride;      // FS mode: second dE/dd slab at pgd + pgd_stride
   bool fs;                 // feature-split mode (host dispatch only)
   const int32_t* npairs;
-  const int64_t* mol_ptr;
+  MolView mol;
   const float* x1;         // [N,128] of this block
   const float* gagg;       // [N,128] dE/d(agg) (backward)
   const float* b0;
@@ -163,7 +180,7 @@ struct NodeBwdArgs {
 
 struct PairsArgs {
   const float* pos;
-  const int64_t* mol_ptr;
+  MolView mol;
   float rc;
   int cap;                 // pair-list capacity per molecule (multiple of 32)
   uint32_t *poi, *poj;
@@ -177,7 +194,7 @@ struct PairsArgs {
 };
 struct SchedArgs {
   const int32_t* npairs;
-  const int64_t* mol_ptr;
+  MolView mol;
   int n_mol, n_split;
   int balanced;            // 1: even out the tiles over the workgroups (one wave of workgroups, n_mol <= 256);
                            // 2: chained -- n_wg workgroups (<= 256) take consecutive chunks of the global tile sequence
@@ -189,7 +206,7 @@ struct SchedArgs {
 };
 struct FinishArgs {
   const float* pos;
-  const int64_t* mol_ptr;
+  MolView mol;
   const uint32_t *poi, *poj;
   const float* pd;
   const float* pgd;

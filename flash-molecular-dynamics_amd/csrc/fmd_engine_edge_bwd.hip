@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 2) void edge_bwd_split_kernel(EdgeArgs a) {
   int tid = tid0;
   asm volatile("" : "+v"(tid));
   const int lane = tid & 63, h = lane >> 5, c32 = lane & 31;
-  const int64_t a0 = a.mol_ptr[m];
-  const int n = min((int)(a.mol_ptr[m + 1] - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
+  const int64_t a0 = grp_begin(a.mol, m);
+  const int n = min((int)(grp_begin(a.mol, m + 1) - a0), a.max_beads);  // LDS is sized for max_beads (pairs_kernel flags a larger molecule)
   const int np = a.npairs[m];
   constexpr int AW = FS ? 64 : F;  // gx1 row width kept in LDS
   if (NEED_GX1)

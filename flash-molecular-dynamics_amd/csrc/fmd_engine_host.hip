@@ -120,6 +120,28 @@ int device_cus() {
 // `cus`: the device's CU count at launch; MAX_CUS when SIZING a workspace (the split falls with the CU count, so the
 // size computed for MAX_CUS covers every device: fmd_schnet_workspace_bytes is device independent)
 constexpr int TAIL_MAX_SPLIT = 4;  // batches larger than the chip: workgroups per molecule tried against the tail
+// Molecule groups (fmd_engine.h MolView): batches of MORE molecules than CUs whose molecules are small run the pair list,
+// the pair kernels and the final reduction over groups of `stride` consecutive molecules -- up to GROUP_BEADS beads and
+// GROUP_MAX molecules per group.  2048 molecules of 10 beads: 82 groups of 25 instead of 2048 two-tile items.
+constexpr int GROUP_MAX = 32;          // molecules per group at most
+constexpr int GROUP_BEADS = 256;       // beads per group at most (the aggregate of a group stays in one workgroup's LDS)
+constexpr int GROUP_MOL_BEADS = 64;    // only molecules up to this size are grouped
+constexpr int64_t GROUP_CAP = 2560;    // pair-list capacity of such a molecule at most (64 * 63 / 2 + 8 * 64 = 2528)
+int group_stride(const fmd_schnet_desc* d, int64_t n_mol, int64_t max_beads, int64_t cap, int cus) {
+  if ((d->flags & FMD_FLAG_NO_MOLECULE_GROUPS) || max_beads > GROUP_MOL_BEADS || cap > GROUP_CAP || n_mol <= cus) return 1;
+  int64_t k = GROUP_BEADS / max_beads;
+  if (k > GROUP_MAX) k = GROUP_MAX;
+  // ... and no larger than what brings the batch down to about one group per CU: a group's workgroup zeroes and flushes
+  // the whole group's aggregate, which for a 250-bead group of 10-bead molecules cost more than its 14 tiles
+  // (profiles/r06_small_molecules.txt: 2048 x 10 beads 0.45 ms with groups of 25, 1024 x 35 beads SLOWER than ungrouped
+  // with groups of 7)
+  const int64_t fill = (n_mol + cus - 1) / cus;
+  if (k > fill) k = fill;
+  return k < 2 ? 1 : (int)k;
+}
+// list arrays are carved per GROUP (stride x the per-molecule capacity): the last, partial group needs up to
+// GROUP_MAX - 1 molecules' worth of room beyond n_mol
+int64_t list_slots(int64_t n_mol, int64_t cap) { return cap <= GROUP_CAP ? n_mol + GROUP_MAX - 1 : n_mol; }
 int resolve_split(const fmd_schnet_desc* d, int64_t n_mol, int cus) {
   if (d->n_split > 0) return d->n_split > MAX_SPLIT ? MAX_SPLIT : d->n_split;
   if (n_mol > cus) {
@@ -198,7 +220,7 @@ bool desc_ok(const fmd_schnet_desc* d) {
   if (d->out_width[d->num_out - 1] != 1) return false;
   if (d->precision != FMD_PREC_F32 && d->precision != FMD_PREC_W16A16) return false;
   if (d->embedding_size < 1) return false;
-  if (d->flags & ~FMD_FLAG_NO_FILTER_STASH) return false;
+  if (d->flags & ~(FMD_FLAG_NO_FILTER_STASH | FMD_FLAG_NO_MOLECULE_GROUPS)) return false;
   // the struct arrives from C callers: a cutoff or gamma that is not a finite positive / finite number must not reach
   // the kernels
   if (!(d->cutoff > 0.f) || !std::isfinite(d->cutoff) || !std::isfinite(d->gamma)) return false;
@@ -318,7 +340,7 @@ extern "C" int64_t fmd_schnet_workspace_bytes(const fmd_schnet_desc* desc, int64
   // cut the molecules into up to TAIL_MAX_SPLIT pieces); >= 2 for the feature-split mode
   int split = resolve_split(desc, n_mol, MAX_CUS);
   if (desc->n_split == 0 && split < TAIL_MAX_SPLIT) split = TAIL_MAX_SPLIT;
-  return carve_ws(desc, nullptr, n_mol, n_nodes, cap, split < 2 ? 2 : split).total + 256;
+  return carve_ws(desc, nullptr, list_slots(n_mol, cap), n_nodes, cap, split < 2 ? 2 : split).total + 256;
 }
 
 static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const float* pos,
@@ -336,10 +358,19 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return FMD_EINVAL;
   hipStream_t s = fmd_stream(stream);
   const int L = desc->num_blocks;
-  const int64_t cap = (max_pairs_per_mol + 31) / 32 * 32;
-  if (cap <= 0 || cap > (int64_t)1 << 30) return FMD_EINVAL;
+  const int64_t cap_mol = (max_pairs_per_mol + 31) / 32 * 32;
+  if (cap_mol <= 0 || cap_mol > (int64_t)1 << 30) return FMD_EINVAL;
   const int cus = device_cus();
-  const int split = fs ? 2 : resolve_split(desc, n_mol, cus);  // FS: the two feature halves
+  // molecule groups: from here on "molecule" means a group of `stride` consecutive molecules (MolView); the caller's
+  // arrays keep their meaning (energy[n_mol_real], mol_ptr[n_mol_real + 1])
+  const int64_t n_mol_real = n_mol;
+  const int stride = fs ? 1 : group_stride(desc, n_mol, max_beads_per_mol, cap_mol, cus);
+  const MolView mv{mol_ptr, n_mol_real, stride};
+  n_mol = (n_mol_real + stride - 1) / stride;
+  max_beads_per_mol *= stride;
+  const int64_t cap = cap_mol * stride;
+  int split = fs ? 2 : resolve_split(desc, n_mol, cus);  // FS: the two feature halves
+  if (stride > 1 && split > TAIL_MAX_SPLIT) split = TAIL_MAX_SPLIT;   // (what fmd_schnet_workspace_bytes sized the slabs for)
   // chained work items (sched_body): more than half but not all CUs would get a molecule of their own
   const bool chain = !fs && desc->n_split == 0 && split == 1 && 2 * n_mol > cus && n_mol < cus && cus <= 256;
   const int n_slabs = chain ? 2 : split;                       // regular slabs the node kernels add
@@ -363,12 +394,12 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   SchedArgs sa;
   {
     PairsArgs pa;
-    pa.pos = pos; pa.mol_ptr = mol_ptr; pa.rc = desc->cutoff; pa.cap = (int)cap; pa.poi = ws.poi; pa.poj = ws.poj;
+    pa.pos = pos; pa.mol = mv; pa.rc = desc->cutoff; pa.cap = (int)cap; pa.poi = ws.poi; pa.poj = ws.poj;
     pa.pd = ws.pd; pa.pc = ws.pc; pa.pdc = ws.pdc; pa.npairs = ws.npairs; pa.report = ws.report;
     pa.max_beads = (int)max_beads_per_mol; pa.forces = forces; pa.extra_row = ws.extra_row; pa.queue = ws.queue;
     // the pair kernels' work items (sched_body in fmd_engine_pairs.hip): balanced when the split is left to the library
     // and the whole launch is one round of workgroups; a caller-given n_split keeps the static tile interleave
-    sa.npairs = ws.npairs; sa.mol_ptr = mol_ptr; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
+    sa.npairs = ws.npairs; sa.mol = mv; sa.n_mol = (int)n_mol; sa.n_split = split; sa.fs = fs ? 1 : 0;
     sa.balanced = chain ? 2 : (!fs && n_mol >= 2 && n_mol <= 256 && n_mol * split <= cus && desc->n_split == 0) ? 1 : 0;
     sa.n_wg = (int)pair_wgs;
     sa.n_nodes = n_nodes; sa.items = ws.items; sa.extra_row = ws.extra_row;
@@ -389,7 +420,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
     EdgeArgs ea;
     ea.items = ws.items;
     ea.poi = ws.poi; ea.poj = ws.poj; ea.pd = ws.pd; ea.pc = ws.pc; ea.pdc = ws.pdc; ea.pgd = ws.pgd; ea.npairs = ws.npairs;
-    ea.mol_ptr = mol_ptr; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
+    ea.mol = mv; ea.x1 = ws.x1[l]; ea.gagg = ws.gagg;
     ea.b0 = pk + o.b0;
     ea.q0h = pk + o.q0h; ea.q0l = pk + o.q0l; ea.q1h = pk + o.q1h; ea.q1l = pk + o.q1l;
     ea.q1th = pk + o.q1th; ea.q1tl = pk + o.q1tl;
@@ -469,7 +500,7 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   }
   {
     FinishArgs fa;
-    fa.pos = pos; fa.mol_ptr = mol_ptr; fa.poi = ws.poi; fa.poj = ws.poj; fa.pd = ws.pd; fa.pgd = ws.pgd;
+    fa.pos = pos; fa.mol = mv; fa.poi = ws.poi; fa.poj = ws.poj; fa.pd = ws.pd; fa.pgd = ws.pgd;
     fa.pgd2 = fs ? ws.pgd + n_mol * cap : nullptr; fa.npairs = ws.npairs; fa.cap = (int)cap; fa.e_node = ws.e_node;
     fa.energy = energy; fa.forces = forces; fa.max_beads = (int)max_beads_per_mol; fa.report = ws.report;
     fa.status = status;

@@ -14,7 +14,7 @@ namespace {
 // one in-register reduction per segment.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ pos,
-                                                    const int64_t* __restrict__ mol_ptr, float rc2,
+                                                    const MolView mol, float rc2,
                                                     float rc, int cap, uint32_t* __restrict__ poi,
                                                     uint32_t* __restrict__ poj,
                                                     float* __restrict__ pd, float* __restrict__ pc,
@@ -30,12 +30,14 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t a0 = mol_ptr[m];
-  int n = (int)(mol_ptr[m + 1] - a0);
+  // (m: a GROUP of mol.stride consecutive molecules, see MolView; max_beads: the bound on a group's beads)
+  const int64_t a0 = grp_begin(mol, m);
+  const int n_all = (int)(grp_begin(mol, m + 1) - a0);
+  int n = n_all;
   if (n > max_beads) {  // the caller's bound is wrong: stay inside the LDS that was sized for it, and say so
     n = max_beads;
   }
-  const bool bad_bound = (int)(mol_ptr[m + 1] - a0) > max_beads;
+  const bool bad_bound = n_all > max_beads;
   if (m == 0 && part == 0 && tid < 16) queue[tid] = 0;   // the pair kernels' item counters (queue mode) of this evaluation
   float* sx = smem;
   float* sy = sx + n;
@@ -44,19 +46,23 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   int* rowstart = cnt + n;                      // [n + 1] offset of the row's run
   int* rowend = rowstart + n + 1;               // [n]     end of the run including its pad entries
   int* conf = rowend + n;                       // [n]     row i must not share an 8-entry segment with the row before
+  int* mid = conf + n;                          // [n]     molecule of the bead inside its group (0 when stride = 1)
   const int NC = (n + 63) >> 6;                 // 64-candidate chunks of a row (at most 9: 535 beads)
   // [n][NC] hit masks: bit b of masks[i NC + c] <-> (i, 64 c + b) is a pair; chunks below (i + 1) / 64 are not written
-  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((7 * n + 2) & ~1));
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(smem + ((8 * n + 2) & ~1));
   __shared__ int tot_s[3];
   for (int i = tid; i < n; i += 1024) {
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
     sz[i] = pos[3 * (a0 + i) + 2];
+    int k = 0;   // the bead's molecule inside the group: how many of the group's later molecules start at or before it
+    for (int j = 1; j < mol.stride; ++j) k += grp_begin(MolView{mol.ptr, mol.n_real, 1}, (int64_t)m * mol.stride + j) - a0 <= i ? 1 : 0;
+    mid[i] = k;
   }
   // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
   if (part == 0) {
-    for (int i = tid; i < 3 * (int)(mol_ptr[m + 1] - a0); i += 1024) forces[3 * a0 + i] = 0.f;
-    for (int i = tid; i < (int)(mol_ptr[m + 1] - a0); i += 1024) extra_row[a0 + i] = -1;  // sched_body names the exceptions
+    for (int i = tid; i < 3 * n_all; i += 1024) forces[3 * a0 + i] = 0.f;
+    for (int i = tid; i < n_all; i += 1024) extra_row[a0 + i] = -1;  // sched_body names the exceptions
   }
   __syncthreads();
   auto dist2 = [&](int i, int j) {
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
   //      beyond the molecule sit at 1e30: their d2 is +inf and never a hit), a wave takes one centre row at a time.
   {
     float px[9], py[9], pz[9];
+    int pm[9];   // the candidates' molecules inside the group: a pair needs both beads in one molecule
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
       const int j = 64 * c + lane;
@@ -74,9 +81,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       px[c] = ok ? sx[j] : 1e30f;
       py[c] = ok ? sy[j] : 1e30f;
       pz[c] = ok ? sz[j] : 1e30f;
+      pm[c] = ok ? mid[j] : -1;
     }
     for (int i = wv; i < n; i += 16) {
       const float xi = sx[i], yi = sy[i], zi = sz[i];
+      const int mi = mid[i];
       const int c_first = (i + 1) >> 6;
       int c_tot = 0;
       unsigned mlo = 0u, mhi = 0u;  // lane c collects the mask of chunk c: one LDS store per row
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
         if (c >= c_first && c < NC) {
           const float dx = px[c] - xi, dy = py[c] - yi, dz = pz[c] - zi;
           const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2);
+          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2 && pm[c] == mi);
           mlo = lane == c ? (unsigned)mk : mlo;
           mhi = lane == c ? (unsigned)(mk >> 32) : mhi;
           c_tot += __popcll(mk);
@@ -373,7 +382,7 @@ __device__ __forceinline__ void sched_body(const SchedArgs& a) {
   if (!a.balanced) {
     for (int64_t w = tid; w < (int64_t)B * S; w += 256) {
       const int m = (int)(w / S), s = (int)(w % S);
-      const int nt = (a.npairs[m] + 31) >> 5, a0 = (int)a.mol_ptr[m];
+      const int nt = (a.npairs[m] + 31) >> 5, a0 = (int)grp_begin(a.mol, m);
       if (a.fs) put(w, 0, m, 0, nt, 1, s * N + a0);  // feature split: both workgroups walk all tiles
       else put(w, 0, m, s, nt, S, s * N + a0);
       put(w, 1, -1, 0, 0, 1, 0);
@@ -393,8 +402,8 @@ __device__ __forceinline__ void sched_body(const SchedArgs& a) {
     const int G = a.n_wg;
     const int t_c = tid < B ? (a.npairs[tid] + 31) >> 5 : 0;
     tt[tid] = t_c;
-    a0c[tid] = tid < B ? (int)a.mol_ptr[tid] : 0;
-    nbc[tid] = tid < B ? (int)(a.mol_ptr[tid + 1] - a.mol_ptr[tid]) : 0;
+    a0c[tid] = tid < B ? (int)grp_begin(a.mol, tid) : 0;
+    nbc[tid] = tid < B ? (int)(grp_begin(a.mol, tid + 1) - grp_begin(a.mol, tid)) : 0;
     if (tid == 0) { tmin_s = 0x7fffffff; tmax_s = 0; }
     __syncthreads();
     if (tid < B) { atomicMin(&tmin_s, t_c); atomicMax(&tmax_s, t_c); }
@@ -448,7 +457,7 @@ __device__ __forceinline__ void sched_body(const SchedArgs& a) {
     return;
   }
   const int t_me = tid < B ? (a.npairs[tid] + 31) >> 5 : 0;
-  const int a0_me = tid < B ? (int)a.mol_ptr[tid] : 0, n_me = tid < B ? (int)(a.mol_ptr[tid + 1] - a.mol_ptr[tid]) : 0;
+  const int a0_me = tid < B ? (int)grp_begin(a.mol, tid) : 0, n_me = tid < B ? (int)(grp_begin(a.mol, tid + 1) - grp_begin(a.mol, tid)) : 0;
   __shared__ int a0_m[256], n_m[256];
   a0_m[tid] = a0_me;
   n_m[tid] = n_me;
@@ -578,7 +587,7 @@ __device__ __forceinline__ float fmd_from_fixed(unsigned long long q) {
   return (float)((double)(long long)q * (1.0 / 4294967296.0));
 }
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
-                                                     const int64_t* __restrict__ mol_ptr,
+                                                     const MolView mol,
                                                      const uint32_t* __restrict__ poi,
                                                      const uint32_t* __restrict__ poj,
                                                      const float* __restrict__ pd,
@@ -592,8 +601,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                                                      int32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int m = blockIdx.y, half = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t a0 = mol_ptr[m];
-  const int n = min((int)(mol_ptr[m + 1] - a0), max_beads);
+  const int64_t a0 = grp_begin(mol, m);
+  const int n = min((int)(grp_begin(mol, m + 1) - a0), max_beads);
   unsigned long long* gall = reinterpret_cast<unsigned long long*>(smem);
   unsigned long long* g = gall + wv * 3 * n;  // this wave's [3n] dE/dpos, fixed point
   __shared__ float esum[4];
@@ -643,11 +652,22 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
     atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
   }
-  if (half == 0) {
+  if (half == 0 && mol.stride == 1) {
     float e = 0.f;
     for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
     e = fmd_wave_sum(e);
     if (lane == 0) esum[wv] = e;
+  } else if (half == 0) {   // a group: one wave per molecule in turn (small molecules: at most 64 beads each)
+    const MolView one{mol.ptr, mol.n_real, 1};
+    for (int j = wv; j < mol.stride; j += 4) {
+      const int64_t mj = (int64_t)m * mol.stride + j;
+      if (mj >= mol.n_real) break;
+      const int64_t b0 = grp_begin(one, mj), b1 = grp_begin(one, mj + 1);
+      float e = 0.f;
+      for (int64_t i = b0 + lane; i < b1; i += 64) e += e_node[i];
+      e = fmd_wave_sum(e);
+      if (lane == 0) energy[mj] = e;
+    }
   }
   if (bad) bad_s = 1;  // (benign race: every writer stores 1)
   __syncthreads();
@@ -657,7 +677,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
                     poisoned ? __builtin_nanf("")
                              : -fmd_from_fixed(((gall[i] + gall[3 * n + i]) + gall[6 * n + i]) + gall[9 * n + i]));
   if (poisoned && tid == 0) atomicMin(&status[3], FMD_ENONFINITE);
-  if (half == 0 && tid == 0) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
+  if (half == 0 && tid == 0 && mol.stride == 1) energy[m] = ((esum[0] + esum[1]) + esum[2]) + esum[3];
   // the call's status words from pairs_kernel's per-molecule reports (one wave of the first workgroup; a bead-bound
   // violation outranks a capacity overflow)
   if (blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) {
@@ -699,14 +719,14 @@ int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s) {
   // positions, counts / offsets / flags, [n][n / 64] 64-bit hit masks (53.5 KB at 535 beads), then the entry staging
   // area: as much of the worst-case list as fits in 128 KB (the list of a 1ENH-sized molecule takes 32 KB)
   const int64_t nb = a.max_beads;
-  const size_t base = (size_t)(7 * nb + 2 + 2 * ((nb + 63) / 64) * nb) * sizeof(float);
+  const size_t base = (size_t)(8 * nb + 2 + 2 * ((nb + 63) / 64) * nb) * sizeof(float);
   const size_t lds = base + (size_t)a.cap * 4 < LDS_PAIRS_MAX ? base + (size_t)a.cap * 4 : LDS_PAIRS_MAX;
   const int ent_cap = (int)((lds - base) / 4);
   // Two workgroups per molecule build the masks and offsets redundantly and fill half of the entries each; below ~100
   // beads the fill is a small part of the kernel and the second workgroup only doubles the launch (1024 molecules of
   // 35 beads: 70 us with two, see profiles/r05_*small_molecules*)
   const unsigned parts = a.max_beads <= 96 ? 1u : 2u;
-  pairs_kernel<<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol_ptr, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
+  pairs_kernel<<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
                                                            a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
                                                            a.forces, ent_cap, a.extra_row, a.queue);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
@@ -721,7 +741,7 @@ int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x
 
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s) {
   finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(unsigned long long), s>>>(
-      a.pos, a.mol_ptr, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
+      a.pos, a.mol, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
       a.report, a.status);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }

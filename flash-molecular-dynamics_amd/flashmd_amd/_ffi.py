@@ -64,7 +64,8 @@ class SchnetDesc(ctypes.Structure):
 
 
 FLAG_NO_FILTER_STASH = 1   # FMD_FLAG_NO_FILTER_STASH
-ABI_VERSION = 5            # what this binding (and engine.py's handling of the status words) was written for
+FLAG_NO_MOLECULE_GROUPS = 2   # FMD_FLAG_NO_MOLECULE_GROUPS
+ABI_VERSION = 6            # what this binding (and engine.py's handling of the status words) was written for
 
 
 class SchnetBlockWeights(ctypes.Structure):

@@ -84,11 +84,15 @@ def _output_weights(on):
 class FusedSchNetEngine:
     """Packed weights + workspace for one model on one device."""
 
-    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True):
+    def __init__(self, model, n_split: int = 0, precision: Optional[str] = None, filter_stash: bool = True,
+                 molecule_groups: bool = True):
         """``precision``: "f32" (default) or "w16a16"; a model whose filter and output networks
         were swapped by ``apply_gptq_w16a16_to_model`` selects "w16a16" by itself.  ``filter_stash=False``: the
         backward pair kernels recompute filter layer 1 instead of reading the values the forward kernels kept
-        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits)."""
+        (FMD_FLAG_NO_FILTER_STASH: smaller workspace, slower, same bits).  ``molecule_groups=False``
+        (FMD_FLAG_NO_MOLECULE_GROUPS): batches of more molecules than CUs whose molecules have at most 64 beads keep one
+        pair list and one work item per molecule instead of per group of up to 32 molecules / 256 beads (slower; a
+        molecule's fp32 sums then do not depend on its neighbours in the batch)."""
         from .schnet import CosineCutoff, GaussianBasis
 
         rbf = model.rbf_layer
@@ -142,7 +146,7 @@ class FusedSchNetEngine:
             raise ValueError(f"fused engine: precision must be one of {sorted(PRECISIONS)}")
         d.precision, d.n_split = PRECISIONS[precision], int(n_split)
         d.cutoff, d.gamma = self.cutoff, float(rbf.coeff.item())
-        d.flags = 0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH
+        d.flags = (0 if filter_stash else _ffi.FLAG_NO_FILTER_STASH) | (0 if molecule_groups else _ffi.FLAG_NO_MOLECULE_GROUPS)
         self._flags = d.flags   # as requested; _workspace() may add FMD_FLAG_NO_FILTER_STASH for a very large batch
         self.desc = d
 

@@ -39,7 +39,9 @@ const char* fmd_strerror(int code);
  *   5: the only flag is FMD_FLAG_NO_FILTER_STASH (the opt-in tabulated-filter prototype of ABI 4, bit 2, left the
  *      product: measured at 0.63x of the MFMA path, DESIGN.md section 3 "Round 4"); desc.cutoff must be finite and
  *      > 0, desc.gamma finite, else FMD_EINVAL; num_rbf up to 128; fmd_overdamped_step; the packed weight layout
- *      changed (fmd_schnet_pack_bytes says how much). */
+ *      changed (fmd_schnet_pack_bytes says how much).
+ *   6: FMD_FLAG_NO_MOLECULE_GROUPS; fmd_schnet_workspace_bytes grew by the room of a partial group for small molecules;
+ *      status word 1 (pair-list entries needed) counts a GROUP of molecules where the engine groups them. */
 int fmd_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -201,7 +203,7 @@ typedef struct fmd_schnet_desc {
                             > 0 = fixed static interleave */
   float cutoff;          /* rc of the cosine cutoff and of the neighbour search */
   float gamma;           /* GaussianBasis.coeff (reference models/radial_basis/gaussian.py:74) */
-  int32_t flags;         /* 0, or FMD_FLAG_NO_FILTER_STASH; any other bit: FMD_EINVAL (ABI 5) */
+  int32_t flags;         /* 0 or an OR of the FMD_FLAG_* below; any other bit: FMD_EINVAL */
 } fmd_schnet_desc;
 /* By default (FMD_PREC_F32 only) the forward pair kernel of every block but the first keeps its filter values W = filt(d) C(d) (fp32, one per
  * list entry and feature: n_mol * max_pairs_per_mol * 512 bytes of workspace per such block, of which the entries a
@@ -209,6 +211,12 @@ typedef struct fmd_schnet_desc {
  * layer 1.  With this flag the workspace stays small and the backward pass recomputes (same results to the last bit:
  * the recomputation runs the same arithmetic). */
 #define FMD_FLAG_NO_FILTER_STASH 1
+/* Batches of MORE molecules than the device has CUs, all of at most 64 beads (max_beads_per_mol), are evaluated over
+ * groups of up to 32 consecutive molecules / 256 beads: one pair list, one aggregate staging and one work item per group
+ * instead of per molecule (a 10-bead molecule is 45 pairs, two tiles: all fixed cost).  Pairs never cross molecules; a
+ * molecule's sums are accumulated in another order than without groups (fp32 rounding), so with this flag the engine
+ * keeps one list per molecule.  The device-side check of max_beads_per_mol then applies to a group's total. */
+#define FMD_FLAG_NO_MOLECULE_GROUPS 2
 
 /* Host pointers to the reference's parameter tensors (fp32, nn.Linear [out,in] layout). */
 typedef struct fmd_schnet_block_weights {

@@ -310,9 +310,13 @@ def test_engine_descriptor_is_validated_without_a_gpu():
         return d
 
     lib = _ffi.lib()
-    assert lib.fmd_abi_version() == _ffi.ABI_VERSION == 5
+    assert lib.fmd_abi_version() == _ffi.ABI_VERSION == 6
     assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc())) > 0
     assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc(flags=_ffi.FLAG_NO_FILTER_STASH))) > 0
-    for bad in (dict(flags=2), dict(flags=3), dict(flags=1 << 20), dict(cutoff=0.0), dict(cutoff=-1.0),
+    assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc(flags=_ffi.FLAG_NO_FILTER_STASH | _ffi.FLAG_NO_MOLECULE_GROUPS))) > 0
+    # the workspace of a batch of small molecules has room for a partial group (ABI 6); large molecules: unchanged rule
+    wb = lib.fmd_schnet_workspace_bytes
+    assert wb(ctypes.byref(desc()), 2048, 20480, 128) > 0
+    for bad in (dict(flags=4), dict(flags=7), dict(flags=1 << 20), dict(cutoff=0.0), dict(cutoff=-1.0),
                 dict(cutoff=float("inf")), dict(cutoff=float("nan")), dict(gamma=float("nan")), dict(gamma=float("inf"))):
         assert lib.fmd_schnet_pack_bytes(ctypes.byref(desc(**bad))) == -1, bad

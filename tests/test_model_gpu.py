@@ -865,8 +865,9 @@ def test_queue_mode_many_small_molecules(params, precision):
     ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
     model = S.model_from_params(params).to(DEV)
     P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
-    queued = engine.FusedSchNetEngine(model, precision=precision)
-    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=1)
+    # (molecule groups off: this test is about the queue, whose bits must equal the plain launch's; groups have their own)
+    queued = engine.FusedSchNetEngine(model, precision=precision, molecule_groups=False)
+    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=1, molecule_groups=False)
     e, f = queued.energy_forces(P, T, Q, 60)
     queued.check_status()
     e1, f1 = plain.energy_forces(P, T, Q, 60)
@@ -891,6 +892,67 @@ def test_queue_mode_many_small_molecules(params, precision):
         g.replay()
     torch.cuda.synchronize()
     queued.check_status()
+    assert torch.equal(e_g, e) and torch.equal(f_g, f)
+
+
+@pytest.mark.parametrize("precision", ["f32", "w16a16"])
+@pytest.mark.parametrize("sizes_kind", ["10", "ragged", "35"])
+def test_molecule_groups_for_batches_of_small_molecules(params, precision, sizes_kind):
+    """Round 6: a batch of MORE molecules than CUs whose molecules have at most 64 beads is evaluated over groups of up to
+    32 consecutive molecules / 256 beads (fmd_engine.h MolView: one pair list, one aggregate staging, one work item per
+    group; pairs never cross molecules).  Against the engine without groups (another summation order: fp32 rounding),
+    against the fp64 oracle on molecules from the first, a middle and the last -- partial -- group, repeat calls
+    bit-identical, single-bead and pair-less molecules inside groups, energies per MOLECULE."""
+    import flashmd_amd.schnet as S
+    from flashmd_amd import engine
+
+    g = torch.Generator().manual_seed(21)
+    if sizes_kind == "10":
+        sizes, bound = [10] * 2049, 10          # 25 per group; the last group holds 24... one molecule more than a multiple
+    elif sizes_kind == "35":
+        sizes, bound = [35] * 600, 35
+    else:
+        sizes, bound = torch.randint(3, 41, (777,), generator=g).tolist(), 40
+    parts = [so.synth_batch(1, n, 5.0, first_mol=k % 97) for k, n in enumerate(sizes)]
+    if sizes_kind == "ragged":   # single beads and a molecule without any pair, inside groups
+        for k in (5, 400):
+            sizes[k] = 1
+            parts[k] = (torch.zeros(1, 3), parts[k][1][:1], None)
+        parts[401] = (torch.tensor([[0.0, 0, 0], [50.0, 0, 0]]), parts[401][1][:2], None)
+        sizes[401] = 2
+    pos = torch.cat([q[0] for q in parts])
+    types = torch.cat([q[1] for q in parts])
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int64)
+    model = S.model_from_params(params).to(DEV)
+    P, T, Q = pos.to(DEV), types.to(DEV), ptr.to(DEV)
+    grouped = engine.FusedSchNetEngine(model, precision=precision)
+    single = engine.FusedSchNetEngine(model, precision=precision, molecule_groups=False)
+    e, f = grouped.energy_forces(P, T, Q, bound)
+    grouped.check_status()
+    e1, f1 = single.energy_forces(P, T, Q, bound)
+    single.check_status()
+    assert e.shape == (len(sizes),) and torch.isfinite(f).all()
+    tol = 2e-3 if precision == "w16a16" else 2e-5
+    assert float((f - f1).norm() / f1.norm()) < tol and float((e - e1).abs().max() / e1.abs().max()) < tol
+    e2, f2 = grouped.energy_forces(P, T, Q, bound)
+    assert torch.equal(e, e2) and torch.equal(f, f2)
+    n_mol = len(sizes)
+    pick = [0, 1, 24, 25, n_mol // 2, n_mol - 2, n_mol - 1] + ([5, 400, 401] if sizes_kind == "ragged" else [])
+    sel = torch.cat([torch.arange(int(ptr[m]), int(ptr[m + 1])) for m in pick])
+    ptr_s = torch.tensor([0] + list(np.cumsum([sizes[m] for m in pick])), dtype=torch.int64)
+    e_o, f_o = so.schnet_energy_forces(so.params_to(params, torch.float64), pos[sel].double(), types[sel], ptr_s)
+    re, rf = _relerr(e.cpu()[pick], f.cpu()[sel], e_o.numpy(), f_o.numpy())
+    print(f"molecule groups, {n_mol} molecules ({sizes_kind}), {precision}: energy {re:.2e} forces {rf:.2e} vs the fp64 oracle")
+    tol = 5e-3 if precision == "w16a16" else 2e-5
+    assert re < tol and rf < tol
+    # under hipGraph capture too
+    gr = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(gr):
+        e_g, f_g = grouped.energy_forces(P, T, Q, bound)
+    gr.replay()
+    torch.cuda.synchronize()
+    grouped.check_status()
     assert torch.equal(e_g, e) and torch.equal(f_g, f)
 
 
@@ -922,8 +984,8 @@ def test_queue_mode_with_split_items_and_wide_basis(params, precision, n_mol, nu
         t = ((n_mol * sp + cus - 1) // cus) / sp * (1.0 + 0.04 * (sp - 1))
         if t < best_t - 1e-9:
             best, best_t = sp, t
-    queued = engine.FusedSchNetEngine(model, precision=precision)
-    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=best)
+    queued = engine.FusedSchNetEngine(model, precision=precision, molecule_groups=False)
+    plain = engine.FusedSchNetEngine(model, precision=precision, n_split=best, molecule_groups=False)
     e, f = queued.energy_forces(P, T, Q, 80)
     queued.check_status()
     e1, f1 = plain.energy_forces(P, T, Q, 80)
