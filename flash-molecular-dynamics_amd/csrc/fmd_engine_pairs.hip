@@ -13,6 +13,9 @@ namespace {
 // distinct, which lets the edge kernels accumulate with plain LDS read-modify-write (no float atomics) and
 // one in-register reduction per segment.
 // ---------------------------------------------------------------------------------------------
+// GROUPED: the "molecule" is a group of mol.stride > 1 consecutive molecules (fmd_engine.h MolView): the hit test also
+// compares the beads' molecules.  The plain instantiation carries none of it.
+template <bool GROUPED>
 __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ pos,
                                                     const MolView mol, float rc2,
                                                     float rc, int cap, uint32_t* __restrict__ poi,
@@ -55,9 +58,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
     sx[i] = pos[3 * (a0 + i)];
     sy[i] = pos[3 * (a0 + i) + 1];
     sz[i] = pos[3 * (a0 + i) + 2];
-    int k = 0;   // the bead's molecule inside the group: how many of the group's later molecules start at or before it
-    for (int j = 1; j < mol.stride; ++j) k += grp_begin(MolView{mol.ptr, mol.n_real, 1}, (int64_t)m * mol.stride + j) - a0 <= i ? 1 : 0;
-    mid[i] = k;
+    if constexpr (GROUPED) {
+      int k = 0;   // the bead's molecule inside the group: how many of the group's later molecules start at or before it
+      for (int j = 1; j < mol.stride; ++j) k += grp_begin(MolView{mol.ptr, mol.n_real, 1}, (int64_t)m * mol.stride + j) - a0 <= i ? 1 : 0;
+      mid[i] = k;
+    }
   }
   // finish_kernel's two workgroups per molecule ADD their halves to the forces: start them from zero
   if (part == 0) {
@@ -81,11 +86,11 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       px[c] = ok ? sx[j] : 1e30f;
       py[c] = ok ? sy[j] : 1e30f;
       pz[c] = ok ? sz[j] : 1e30f;
-      pm[c] = ok ? mid[j] : -1;
+      pm[c] = (GROUPED && ok) ? mid[j] : 0;
     }
     for (int i = wv; i < n; i += 16) {
       const float xi = sx[i], yi = sy[i], zi = sz[i];
-      const int mi = mid[i];
+      const int mi = GROUPED ? mid[i] : 0;
       const int c_first = (i + 1) >> 6;
       int c_tot = 0;
       unsigned mlo = 0u, mhi = 0u;  // lane c collects the mask of chunk c: one LDS store per row
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
         if (c >= c_first && c < NC) {
           const float dx = px[c] - xi, dy = py[c] - yi, dz = pz[c] - zi;
           const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2 && pm[c] == mi);
+          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2 && (!GROUPED || pm[c] == mi));
           mlo = lane == c ? (unsigned)mk : mlo;
           mhi = lane == c ? (unsigned)(mk >> 32) : mhi;
           c_tot += __popcll(mk);
@@ -711,7 +716,10 @@ namespace fmd_eng {
 constexpr size_t LDS_PAIRS_MAX = 128 * 1024;
 
 int setup_pairs_attrs() {
-  return hipFuncSetAttribute((const void*)pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute((const void*)pairs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)LDS_PAIRS_MAX) != hipSuccess)
+    return FMD_ELAUNCH;
+  return hipFuncSetAttribute((const void*)pairs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)LDS_PAIRS_MAX) == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
 
@@ -726,9 +734,14 @@ int launch_pairs(const PairsArgs& a, int64_t n_mol, hipStream_t s) {
   // beads the fill is a small part of the kernel and the second workgroup only doubles the launch (1024 molecules of
   // 35 beads: 70 us with two, see profiles/r05_*small_molecules*)
   const unsigned parts = a.max_beads <= 96 ? 1u : 2u;
-  pairs_kernel<<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
-                                                           a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
-                                                           a.forces, ent_cap, a.extra_row, a.queue);
+  if (a.mol.stride > 1)
+    pairs_kernel<true><<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
+                                                                 a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
+                                                                 a.forces, ent_cap, a.extra_row, a.queue);
+  else
+    pairs_kernel<false><<<dim3(parts, (unsigned)n_mol), 1024, lds, s>>>(a.pos, a.mol, a.rc * a.rc, a.rc, a.cap, a.poi, a.poj,
+                                                                  a.pd, a.pc, a.pdc, a.npairs, a.report, a.max_beads,
+                                                                  a.forces, ent_cap, a.extra_row, a.queue);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
 }
 
