@@ -381,6 +381,9 @@ static int run_engine(const fmd_schnet_desc* desc, const void* packed_dev, const
   const int64_t pair_wgs = chain || queue ? cus : n_mol;       // grid.y of the pair kernels
   if ((int64_t)(n_slabs + 1) * n_nodes >= ((int64_t)1 << 31)) return FMD_EUNSUPPORTED;  // slab rows are 32-bit in the work items
   const Workspace ws = carve_ws(desc, workspace, n_mol, n_nodes, cap, n_slabs);
+  // the carve of THIS launch configuration (groups, split) must fit what fmd_schnet_workspace_bytes told the caller to
+  // allocate for the batch -- pure arithmetic, checked on every call
+  if (ws.total + 256 > fmd_schnet_workspace_bytes(desc, n_mol_real, n_nodes, max_pairs_per_mol)) return FMD_EINVAL;
   const PackLayout PL = pack_layout(desc);
   const float* pk = reinterpret_cast<const float*>(packed_dev);
 
