@@ -305,8 +305,9 @@ class FusedSchNetEngine:
         code = st[0] or st[3]
         if code != 0:
             when = "the last evaluation" if st[0] else "an evaluation since the previous status read"
-            raise RuntimeError(f"fused engine: device status {code} ({_ffi.strerror(code)}) in {when}; max pairs seen "
-                               f"in one molecule {st[1]}, total pairs {st[2]}: energies and forces of that call are invalid")
+            raise RuntimeError(f"fused engine: device status {code} ({_ffi.strerror(code)}) in {when}; max list entries "
+                               f"needed by one molecule (or molecule group) {st[1]}, total pairs {st[2]}: energies and forces "
+                               "of that call are invalid")
         return st
 
 
