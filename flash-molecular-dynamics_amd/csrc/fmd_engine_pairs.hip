@@ -615,47 +615,69 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   bool bad = false;  // a contribution that the fixed-point sum cannot carry (Inf, NaN, |x| >= FMD_FIXED_LIMIT)
   if (tid == 0) bad_s = 0;
   for (int i = tid; i < 12 * n; i += 256) gall[i] = 0ull;
+  float* const spos = reinterpret_cast<float*>(gall + 12 * n);   // [3 n] positions of the molecule
+  for (int i = tid; i < 3 * n; i += 256) spos[i] = pos[3 * a0 + i];
   __syncthreads();
   const int np = npairs[m];
   const int np_half = ((np + 15) >> 4) << 3;  // the first workgroup's share (whole 8-entry segments)
   const int q_lo = half ? min(np, np_half) : 0, q_hi = half ? np : min(np, np_half);
-  // every thread walks a contiguous run of the (centre-sorted) list: the centre's contribution is
-  // summed in registers and flushed when the centre changes, so lanes rarely collide in LDS
-  const int chunk = (q_hi - q_lo + 255) / 256;
-  const int p_lo = min(q_hi, q_lo + tid * chunk), p_hi = min(q_hi, p_lo + chunk);
-  int ci = -1;
-  float cx = 0.f, cy = 0.f, cz = 0.f;
-  for (int p = p_lo; p < p_hi; ++p) {
-    const int i = (int)(poi[(int64_t)m * cap + p] / (F * 4));
-    const int j = (int)(poj[(int64_t)m * cap + p] / (F * 4));
-    if (i != ci) {
-      if (ci >= 0) {
-        atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
-        atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
-        atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
+  // Every thread takes GROUPS of eight consecutive entries of the (centre-sorted) list -- 32 contiguous bytes of each
+  // list array, fetched as two 16-byte loads per array, all of a group's loads in flight together, a wave's loads 2 KB
+  // of contiguous memory (round 6: the former walk, one entry at a time with a per-thread stride of ~15 entries, was a
+  // chain of ~15 uncoalesced round trips; 20.3 -> 15.4 us, profiles/r06_ab_finish.txt).  Inside a group the centre's
+  // contribution is summed in registers and flushed when the centre changes, so lanes rarely collide in LDS.  The
+  // positions come from LDS.  (q_lo, q_hi and the list base are multiples of 8 entries: the loads are aligned.)
+  const uint32_t* const poi_m = poi + (int64_t)m * cap;
+  const uint32_t* const poj_m = poj + (int64_t)m * cap;
+  const float* const pd_m = pd + (int64_t)m * cap;
+  const float* const pgd_m = pgd + (int64_t)m * cap;
+  const float* const pgd2_m = pgd2 ? pgd2 + (int64_t)m * cap : nullptr;
+  for (int p0 = q_lo + 8 * tid; p0 < q_hi; p0 += 8 * 256) {
+    u32x4 vi[2], vj[2];
+    f32x4 vd[2], vg[2], vg2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      vi[u] = *reinterpret_cast<const u32x4*>(poi_m + p0 + 4 * u);
+      vj[u] = *reinterpret_cast<const u32x4*>(poj_m + p0 + 4 * u);
+      vd[u] = *reinterpret_cast<const f32x4*>(pd_m + p0 + 4 * u);
+      vg[u] = *reinterpret_cast<const f32x4*>(pgd_m + p0 + 4 * u);
+      vg2[u] = pgd2_m ? *reinterpret_cast<const f32x4*>(pgd2_m + p0 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int ci = -1;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = (int)(vi[e >> 2][e & 3] / (F * 4));
+      const int j = (int)(vj[e >> 2][e & 3] / (F * 4));
+      if (i != ci) {
+        if (ci >= 0) {
+          atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
+          atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
+          atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
+        }
+        ci = i;
+        cx = cy = cz = 0.f;
       }
-      ci = i;
-      cx = cy = cz = 0.f;
+      if (i != j) {  // pad entries carry nothing
+        const float d = fmaxf(vd[e >> 2][e & 3], 1e-8f);
+        const float gdd = vg[e >> 2][e & 3] + (pgd2_m ? vg2[e >> 2][e & 3] : 0.f);
+        const float s = gdd / d;
+        const float dx = s * (spos[3 * j] - spos[3 * i]);
+        const float dy = s * (spos[3 * j + 1] - spos[3 * i + 1]);
+        const float dz = s * (spos[3 * j + 2] - spos[3 * i + 2]);
+        atomicAdd(&g[3 * j], fmd_to_fixed(dx, bad));
+        atomicAdd(&g[3 * j + 1], fmd_to_fixed(dy, bad));
+        atomicAdd(&g[3 * j + 2], fmd_to_fixed(dz, bad));
+        cx -= dx;
+        cy -= dy;
+        cz -= dz;
+      }
     }
-    if (i != j) {  // pad entries carry nothing
-      const float d = fmaxf(pd[(int64_t)m * cap + p], 1e-8f);
-      const float gdd = pgd[(int64_t)m * cap + p] + (pgd2 ? pgd2[(int64_t)m * cap + p] : 0.f);
-      const float s = gdd / d;
-      const float dx = s * (pos[3 * (a0 + j)] - pos[3 * (a0 + i)]);
-      const float dy = s * (pos[3 * (a0 + j) + 1] - pos[3 * (a0 + i) + 1]);
-      const float dz = s * (pos[3 * (a0 + j) + 2] - pos[3 * (a0 + i) + 2]);
-      atomicAdd(&g[3 * j], fmd_to_fixed(dx, bad));
-      atomicAdd(&g[3 * j + 1], fmd_to_fixed(dy, bad));
-      atomicAdd(&g[3 * j + 2], fmd_to_fixed(dz, bad));
-      cx -= dx;
-      cy -= dy;
-      cz -= dz;
+    if (ci >= 0) {
+      atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
+      atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
+      atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
     }
-  }
-  if (ci >= 0) {
-    atomicAdd(&g[3 * ci], fmd_to_fixed(cx, bad));
-    atomicAdd(&g[3 * ci + 1], fmd_to_fixed(cy, bad));
-    atomicAdd(&g[3 * ci + 2], fmd_to_fixed(cz, bad));
   }
   if (half == 0 && mol.stride == 1) {
     float e = 0.f;
@@ -753,7 +775,8 @@ int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x
 }
 
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s) {
-  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(unsigned long long), s>>>(
+  // four per-wave copies of dE/dpos in 64-bit fixed point, then the molecule's positions
+  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(unsigned long long) + 3 * (size_t)a.max_beads * sizeof(float), s>>>(
       a.pos, a.mol, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
       a.report, a.status);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
