@@ -92,19 +92,26 @@ __global__ __launch_bounds__(1024) void pairs_kernel(const float* __restrict__ p
       const float xi = sx[i], yi = sy[i], zi = sz[i];
       const int mi = GROUPED ? mid[i] : 0;
       const int c_first = (i + 1) >> 6;
+      // Branch-free chunk body (round 6): a lane of the row's FIRST chunk is a candidate only above the centre -- a scalar
+      // mask on the ballot instead of a per-lane test (beyond the first chunk 64 c + lane > i always holds) --, and the
+      // ballot goes into lane c of the mask registers with v_writelane.  The compiler had turned the two-sided
+      // test into nested exec-mask regions, ~30 instructions and two branches per chunk (profiles/r06_pairs_phases.txt).
+      const unsigned long long first_mask = ~0ull << ((i + 1) & 63);
       int c_tot = 0;
       unsigned mlo = 0u, mhi = 0u;  // lane c collects the mask of chunk c: one LDS store per row
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        if (c >= c_first && c < NC) {
+      static_for<0, 9>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if (c >= c_first && c < NC) {   // (wave-uniform)
           const float dx = px[c] - xi, dy = py[c] - yi, dz = pz[c] - zi;
           const float d2 = (dx * dx + dy * dy) + dz * dz;
-          const unsigned long long mk = __ballot(64 * c + lane > i && d2 < rc2 && (!GROUPED || pm[c] == mi));
-          mlo = lane == c ? (unsigned)mk : mlo;
-          mhi = lane == c ? (unsigned)(mk >> 32) : mhi;
+          unsigned long long mk = __ballot(GROUPED ? (d2 < rc2) & (pm[c] == mi) : d2 < rc2);
+          if (c == c_first) mk &= first_mask;
+          // (no clang builtin for v_writelane_b32; the lane select is an inline constant: gfx9's one-SGPR limit)
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((unsigned)mk), "n"(c));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((unsigned)(mk >> 32)), "n"(c));
           c_tot += __popcll(mk);
         }
-      }
+      });
       if (lane < NC) masks[i * NC + lane] = ((unsigned long long)mhi << 32) | mlo;  // (zero below c_first)
       if (lane == 0) cnt[i] = c_tot;
     }
