@@ -1,3 +1,4 @@
+"""Phase times of pairs_kernel from the stamped throw-away build (tools/diag/pairs_stamps_patch.py -> gpurun_ab/lib_pairs_stamps.so)."""
 import os, sys, ctypes
 import torch
 sys.path[:0] = [".", "flash-molecular-dynamics_amd"]
