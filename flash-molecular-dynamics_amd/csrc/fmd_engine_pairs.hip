@@ -598,7 +598,11 @@ __device__ __forceinline__ unsigned long long fmd_to_fixed(float x, bool& bad) {
 __device__ __forceinline__ float fmd_from_fixed(unsigned long long q) {
   return (float)((double)(long long)q * (1.0 / 4294967296.0));
 }
-__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ pos,
+// threads of a finish_kernel workgroup: the kernel is a stream of scattered 64-bit LDS atomics (~229 cycles each for a lone
+// wave), and sixteen waves keep four times as many in flight as four (same-box A/B, profiles/r06_ab_finish.txt: 16.3 us with
+// 256 threads, 12.7 with 512, 11.3 with 1024; the same bits -- the groups of eight entries do not depend on who takes them)
+constexpr int FIN_NT = 1024;
+__global__ __launch_bounds__(FIN_NT) void finish_kernel(const float* __restrict__ pos,
                                                      const MolView mol,
                                                      const uint32_t* __restrict__ poi,
                                                      const uint32_t* __restrict__ poj,
@@ -616,14 +620,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   const int64_t a0 = grp_begin(mol, m);
   const int n = min((int)(grp_begin(mol, m + 1) - a0), max_beads);
   unsigned long long* gall = reinterpret_cast<unsigned long long*>(smem);
-  unsigned long long* g = gall + wv * 3 * n;  // this wave's [3n] dE/dpos, fixed point
+  unsigned long long* g = gall + (wv & 3) * 3 * n;  // this wave's [3n] dE/dpos, fixed point (four copies: waves w, w + 4, ... share one)
   __shared__ float esum[4];
   __shared__ int bad_s;
   bool bad = false;  // a contribution that the fixed-point sum cannot carry (Inf, NaN, |x| >= FMD_FIXED_LIMIT)
   if (tid == 0) bad_s = 0;
-  for (int i = tid; i < 12 * n; i += 256) gall[i] = 0ull;
+  for (int i = tid; i < 12 * n; i += FIN_NT) gall[i] = 0ull;
   float* const spos = reinterpret_cast<float*>(gall + 12 * n);   // [3 n] positions of the molecule
-  for (int i = tid; i < 3 * n; i += 256) spos[i] = pos[3 * a0 + i];
+  for (int i = tid; i < 3 * n; i += FIN_NT) spos[i] = pos[3 * a0 + i];
   __syncthreads();
   const int np = npairs[m];
   const int np_half = ((np + 15) >> 4) << 3;  // the first workgroup's share (whole 8-entry segments)
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   const float* const pd_m = pd + (int64_t)m * cap;
   const float* const pgd_m = pgd + (int64_t)m * cap;
   const float* const pgd2_m = pgd2 ? pgd2 + (int64_t)m * cap : nullptr;
-  for (int p0 = q_lo + 8 * tid; p0 < q_hi; p0 += 8 * 256) {
+  for (int p0 = q_lo + 8 * tid; p0 < q_hi; p0 += 8 * FIN_NT) {
     u32x4 vi[2], vj[2];
     f32x4 vd[2], vg[2], vg2[2];
 #pragma unroll
@@ -687,13 +691,15 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
     }
   }
   if (half == 0 && mol.stride == 1) {
-    float e = 0.f;
-    for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
-    e = fmd_wave_sum(e);
-    if (lane == 0) esum[wv] = e;
+    if (wv < 4) {   // (the first four waves, whatever the workgroup size: the energy's summation order is part of the result)
+      float e = 0.f;
+      for (int i = tid; i < n; i += 256) e += e_node[a0 + i];
+      e = fmd_wave_sum(e);
+      if (lane == 0) esum[wv] = e;
+    }
   } else if (half == 0) {   // a group: one wave per molecule in turn (small molecules: at most 64 beads each)
     const MolView one{mol.ptr, mol.n_real, 1};
-    for (int j = wv; j < mol.stride; j += 4) {
+    for (int j = wv; j < mol.stride; j += FIN_NT / 64) {
       const int64_t mj = (int64_t)m * mol.stride + j;
       if (mj >= mol.n_real) break;
       const int64_t b0 = grp_begin(one, mj), b1 = grp_begin(one, mj + 1);
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ p
   if (bad) bad_s = 1;  // (benign race: every writer stores 1)
   __syncthreads();
   const bool poisoned = bad_s != 0;
-  for (int i = tid; i < 3 * n; i += 256)
+  for (int i = tid; i < 3 * n; i += FIN_NT)
     unsafeAtomicAdd(&forces[3 * a0 + i],
                     poisoned ? __builtin_nanf("")
                              : -fmd_from_fixed(((gall[i] + gall[3 * n + i]) + gall[6 * n + i]) + gall[9 * n + i]));
@@ -783,7 +789,7 @@ int launch_node_embed(const int64_t* types, const float* emb, const float* emb_x
 
 int launch_finish(const FinishArgs& a, int64_t n_mol, hipStream_t s) {
   // four per-wave copies of dE/dpos in 64-bit fixed point, then the molecule's positions
-  finish_kernel<<<dim3(2, (unsigned)n_mol), 256, 12 * (size_t)a.max_beads * sizeof(unsigned long long) + 3 * (size_t)a.max_beads * sizeof(float), s>>>(
+  finish_kernel<<<dim3(2, (unsigned)n_mol), FIN_NT, 12 * (size_t)a.max_beads * sizeof(unsigned long long) + 3 * (size_t)a.max_beads * sizeof(float), s>>>(
       a.pos, a.mol, a.poi, a.poj, a.pd, a.pgd, a.pgd2, a.npairs, a.cap, a.e_node, a.energy, a.forces, a.max_beads,
       a.report, a.status);
   return hipGetLastError() == hipSuccess ? FMD_OK : FMD_ELAUNCH;
